@@ -1,0 +1,82 @@
+"""oracle/xlsr_ref.py vs HuggingFace Wav2Vec2Model (independent restatement of the same
+architecture).  This does NOT pin equality with the reference's fairseq checkpoint path --
+fairseq is absent from the reference tree and the image -- see oracle/xlsr_ref.py header."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import xlsr_ref
+from oracle.fill import fill_like
+
+transformers = pytest.importorskip("transformers")
+
+
+def _hf_model(cfg, p):
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    hc = Wav2Vec2Config(hidden_size=cfg.dim, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                        intermediate_size=cfg.ffn, feat_extract_norm="layer", conv_bias=True,
+                        do_stable_layer_norm=True, num_conv_pos_embeddings=cfg.pos_k,
+                        num_conv_pos_embedding_groups=cfg.pos_groups, hidden_dropout=0.0,
+                        attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0,
+                        layerdrop=0.0, apply_spec_augment=False)
+    m = Wav2Vec2Model(hc).eval()
+    sd = m.state_dict()
+    ren = {}
+    for i in range(7):
+        a, b = "feature_extractor.conv_layers.%d" % i, "feature_extractor.conv_layers.%d" % i
+        ren[a + ".conv.weight"] = b + ".0.weight"; ren[a + ".conv.bias"] = b + ".0.bias"
+        ren[a + ".layer_norm.weight"] = b + ".2.1.weight"; ren[a + ".layer_norm.bias"] = b + ".2.1.bias"
+    ren["feature_projection.layer_norm.weight"] = "layer_norm.weight"
+    ren["feature_projection.layer_norm.bias"] = "layer_norm.bias"
+    ren["feature_projection.projection.weight"] = "post_extract_proj.weight"
+    ren["feature_projection.projection.bias"] = "post_extract_proj.bias"
+    ren["encoder.pos_conv_embed.conv.bias"] = "encoder.pos_conv.0.bias"
+    ren["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = "encoder.pos_conv.0.weight_g"
+    ren["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = "encoder.pos_conv.0.weight_v"
+    ren["encoder.layer_norm.weight"] = "encoder.layer_norm.weight"
+    ren["encoder.layer_norm.bias"] = "encoder.layer_norm.bias"
+    for i in range(cfg.layers):
+        a, b = "encoder.layers.%d" % i, "encoder.layers.%d" % i
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            for w in ("weight", "bias"):
+                ren["%s.attention.%s.%s" % (a, n, w)] = "%s.self_attn.%s.%s" % (b, n, w)
+        for w in ("weight", "bias"):
+            ren["%s.layer_norm.%s" % (a, w)] = "%s.self_attn_layer_norm.%s" % (b, w)
+            ren["%s.feed_forward.intermediate_dense.%s" % (a, w)] = "%s.fc1.%s" % (b, w)
+            ren["%s.feed_forward.output_dense.%s" % (a, w)] = "%s.fc2.%s" % (b, w)
+            ren["%s.final_layer_norm.%s" % (a, w)] = "%s.final_layer_norm.%s" % (b, w)
+    new = {}
+    for k, v in sd.items():
+        if k in ren:
+            assert tuple(v.shape) == tuple(p[ren[k]].shape), (k, v.shape, p[ren[k]].shape)
+            new[k] = p[ren[k]].clone()
+        else:
+            assert k == "masked_spec_embed", k
+            new[k] = v
+    assert len(set(ren.values())) == len(p), (len(ren), len(p))
+    m.load_state_dict(new, strict=True)
+    return m
+
+
+@pytest.mark.parametrize("L,layers", [(16000, 2), (4000, 3)])
+def test_xlsr_oracle_matches_hf_proxy(L, layers):
+    cfg = xlsr_ref.XlsrConfig(dim=256, ffn=512, heads=4, layers=layers, pos_k=128, pos_groups=16)
+    p = fill_like(xlsr_ref.param_shapes(cfg), seed=3)
+    wav = 0.1 * torch.randn(2, L, generator=torch.Generator().manual_seed(5))
+    taps = {}
+    with torch.no_grad():
+        mine = xlsr_ref.extract_feat(wav, p, cfg, taps)
+        hf = _hf_model(cfg, p)
+        out = hf(wav)
+    assert mine.shape == (2, xlsr_ref.n_frames(L), cfg.dim)
+    # HF's ``extract_features`` is the conv stack output AFTER feature_projection.layer_norm
+    normed = torch.nn.functional.layer_norm(taps["conv"], (512,), p["layer_norm.weight"], p["layer_norm.bias"])
+    np.testing.assert_allclose(normed.numpy(), out.extract_features.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(mine.numpy(), out.last_hidden_state.numpy(), rtol=1e-3, atol=2e-4)
+
+
+def test_flop_formula_matches_survey():
+    f = xlsr_ref.flops_forward(64000, xlsr_ref.XlsrConfig.xlsr_300m())
+    assert xlsr_ref.n_frames(64000) == 199 and xlsr_ref.n_frames(64600) == 201
+    assert abs(f["total"] / 1e9 - 147.275) < 0.01 and abs(f["fe"] / 1e9 - 19.626) < 0.001
+    assert abs(xlsr_ref.flops_forward(64000, xlsr_ref.XlsrConfig.xlsr_1b())["total"] / 1e9 - 410.462) < 0.01
