@@ -1,0 +1,126 @@
+/* libocc_hip.so -- C ABI of the MI355X (gfx950) implementation of the occm training hot path.
+ *
+ * The reference (nguyenvulong/occm) is pure Python on PyTorch and has no FFI layer of its own;
+ * each entry point below names the reference Python function (file:line in the upstream tree)
+ * whose arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in _host;
+ *   - shapes are int64_t, row-major, innermost dimension contiguous unless a stride is passed;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it;
+ *   - return value: 0 on success, a negative occ_status otherwise; occ_last_error() returns a
+ *     thread-local message for the most recent failure on the calling thread;
+ *   - the library keeps no global mutable state and never allocates device memory.
+ */
+#ifndef OCC_HIP_H
+#define OCC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum occ_status { OCC_OK = 0, OCC_EINVAL = -1, OCC_ELAUNCH = -2, OCC_EUNSUPPORTED = -3 };
+enum occ_dtype { OCC_F32 = 0, OCC_BF16 = 1, OCC_F64 = 2 };
+enum occ_act { OCC_ACT_NONE = 0, OCC_ACT_GELU = 1, OCC_ACT_SELU = 2, OCC_ACT_RELU = 3, OCC_ACT_TANH = 4 };
+
+const char* occ_last_error(void);
+int occ_version(void);
+const char* occ_arch(void);            /* "gfx950" */
+
+/* ---------------------------------------------------------------- RawBoost (RawBoost.py) -- */
+/* y[b,j] = sum_i sum_k coef[b,i,k] * pow(x[b, j + (ntaps[b,i]+1)/2 - k], i+1 if powers else 1),
+ * zero outside [0,L): filterFIR (RawBoost.py:51-56) summed over the N_f branches of
+ * LnL_convolutive_noise (:59-66).  x: f32 or f64 [B,L]; y: f64 [B,L]; coef: f64 [B,n_filt,max_taps];
+ * ntaps: i32 [B,n_filt] (odd, <= max_taps <= 1024).                                             */
+int occ_rawboost_fir_bank(const void* x, int x_dtype, double* y, const double* coef, const int32_t* ntaps,
+                          int64_t B, int64_t L, int64_t n_filt, int64_t max_taps, int powers, void* stream);
+/* In place on y f64 [B,L]: optional mean removal, then peak normalisation (mode 1: only when the
+ * peak exceeds 1 -- normWav(x,0); mode 2: always -- normWav(x,1); mode 0: none).  RawBoost.py:20-25,
+ * 67-68.  partials: f64 scratch [B, ceil(L/4096), 4].                                            */
+int occ_rawboost_center_norm(double* y, int64_t B, int64_t L, int subtract_mean, int norm_mode,
+                             double* partials, void* stream);
+/* ISD_additive_noise scatter (RawBoost.py:78-82): y[b,pos] = y[b,pos]*(1 + g_sd*fr) for the first
+ * n[b] entries of pos/fr ([B,max_n]).  Follow with occ_rawboost_center_norm(.., 0, 1, ..).        */
+int occ_rawboost_isd_scatter(double* y, const int32_t* pos, const double* fr, const int32_t* n,
+                             int64_t B, int64_t L, int64_t max_n, double g_sd, void* stream);
+/* SSI_additive_noise mix (RawBoost.py:93-96): out = x + noise/||noise||*||x||/10^(0.05*snr[b]);
+ * noise must already be filtered and peak-normalised.  partials: f64 scratch [B, ceil(L/4096), 4]. */
+int occ_rawboost_ssi_mix(const double* x, const double* noise, const double* snr, double* out,
+                         int64_t B, int64_t L, double* partials, void* stream);
+/* HOST function (no GPU work): genNotchCoeffs (RawBoost.py:28-48) for caller-drawn (fc,bw,c)[n_bands], G.
+ * Writes max_taps doubles (zero padded) to out_host and the tap count to ntaps_out_host.          */
+int occ_notch_coeffs_host(const double* fc, const double* bw, const int32_t* c, int64_t n_bands, double G, double fs,
+                          double* out_host, int32_t* ntaps_out_host, int64_t max_taps);
+/* out = a + b (f64): the parallel branch sum of RawBoost algo 8 (data_utils_SSL.py:160-165).         */
+int occ_add_f64(const double* a, const double* b, double* out, int64_t n, void* stream);
+int occ_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* Counter-based N(0,1) / U[0,1) fill (Philox4x32-10), element i uses counter (i/4, stream_id).   */
+int occ_philox_fill(void* dst, int dtype, int64_t n, uint64_t seed, uint64_t stream_id, int normal, void* stream);
+
+/* ---------------------------------------------------- losses (losses/custom_loss.py) ------ */
+/* compactness_loss (custom_loss.py:4-29) over groups of `group` rows: rows [g*group, g*group+6) of
+ * emb f32 [n_groups*group, E]; loss[0] = mean over groups of the reference's 6-row value.
+ * demb (may be NULL) receives d(loss*scale)/demb (zeros for rows 6.. of each group).             */
+int occ_compactness_loss(const float* emb, float* loss, float* demb, int64_t n_groups, int64_t group,
+                         int64_t E, float scale, void* stream);
+/* descriptiveness_loss (custom_loss.py:78-99): mean cross-entropy of logits f32 [B,C] vs labels i64 [B];
+ * dlogits (may be NULL) receives d(loss*scale)/dlogits.                                          */
+int occ_ce_loss(const float* logits, const int64_t* labels, float* loss, float* dlogits, int64_t B,
+                int64_t C, float scale, void* stream);
+/* F.pairwise_distance(ref, emb) of oc_classifier.py:193, 261: dist[i] = ||ref - emb[i] + 1e-6||_2.  */
+int occ_pairwise_dist(const float* ref, const float* emb, float* dist, int64_t N, int64_t E, void* stream);
+
+/* ---------------------------------------------------- optimizer (oc_training.py:324, 385) -- */
+/* torch.optim.Adam step (no weight decay, no amsgrad) over a list of n tensors given as device
+ * arrays of pointers/sizes: p -= lr * m_hat / (sqrt(v_hat) + eps).  step >= 1.                    */
+int occ_adam_multi(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                   const int64_t* sizes, int64_t n_tensors, int64_t max_size, float lr, float beta1,
+                   float beta2, float eps, int64_t step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ GEMM family ----------- */
+/* Row addressing shared by A, C and the residual R: row m lives at
+ *     base + (m / rows_per_batch) * batch_stride + (m % rows_per_batch) * row_stride     (elements)
+ * which expresses plain matrices (rows_per_batch = M), strided-window implicit GEMMs (Conv1d over a
+ * channels-last signal: row_stride = stride*C, K = k*C) and writes into zero-padded buffers.
+ * A rows may additionally be split into `a_nseg` K-segments of `a_seg_len` contiguous elements that
+ * are `a_seg_stride` apart (grouped / 2-D convolutions); a_nseg*a_seg_len == K.                   */
+typedef struct occ_rowmap { int64_t rows_per_batch, batch_stride, row_stride; } occ_rowmap;
+typedef struct occ_gemm_desc {
+    int64_t M, N, K;
+    const void* A; occ_rowmap a_map; int64_t a_nseg, a_seg_len, a_seg_stride;
+    const void* W; int64_t ldw;                /* W[N,K] row-major (torch Linear layout), K contiguous */
+    const void* bias;                          /* f32 [N] or NULL */
+    const void* R; occ_rowmap r_map; int r_dtype;   /* residual added after activation, or NULL */
+    void* C; occ_rowmap c_map; int c_dtype;
+    int ab_dtype;                              /* OCC_BF16: bf16 MFMA (f32 accumulate); OCC_F32: f32 MFMA */
+    int act;                                   /* occ_act applied to (acc + bias) */
+    float alpha;                               /* acc scaled by alpha before bias */
+    /* grouped problems (grouped Conv1d): group g uses A + g*a_group_stride, W + g*w_group_stride and
+     * output/bias/residual columns shifted by g*c_group_stride; n_groups <= 1 means a single problem. */
+    int64_t n_groups, a_group_stride, w_group_stride, c_group_stride;
+} occ_gemm_desc;
+/* C = act(alpha * A.W^T + bias) + R.  Replaces every nn.Linear / Conv1d of the path
+ * (fairseq wav2vec2 layers reached from sslassist.py:48; AModel.LL sslassist.py:509).             */
+int occ_gemm(const occ_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------- front-end row kernels ------- */
+/* y = LayerNorm(x) * gamma + beta, optional GELU, over rows of width C (C % 64 == 0, C <= 8192).
+ * fairseq LayerNorm / Fp32LayerNorm + GELU of the conv blocks and transformer layers.            */
+int occ_layernorm(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta,
+                  int64_t rows, int64_t C, float eps, int gelu, void* stream);
+/* First conv block of the wav2vec2 feature extractor fused: Conv1d(1->C,k,stride,bias) -> LayerNorm(C)
+ * -> GELU.  wav f32 [B,L] -> out [B,Tout,C] (channels-last).  w f32 [C,k]; C == 512, k <= 16.       */
+int occ_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const float* gamma,
+                      const float* beta, void* out, int out_dtype, int64_t B, int64_t L, int64_t Tout,
+                      int64_t C, int64_t k, int64_t stride, float eps, void* stream);
+/* Multi-head self-attention core softmax(Q.K^T).V for short sequences (T <= 1024), head_dim 64/80.
+ * qkv: [B*T, 3*D] rows (q | k | v); scores are scale * q.k (fairseq scales q by hd^-0.5); out: [B*T, D].  */
+int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd,
+                  int64_t ld_qkv, int64_t ld_out, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+"""ctypes binding of libocc_hip.so.  Prototypes are read from include/occ_hip.h so the header is the
+single source of truth for the ABI.  Loading fails loudly: the product has no fallback path."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "occ_hip.h")
+
+OCC_F32, OCC_BF16, OCC_F64 = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_SELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
+
+
+class OccError(RuntimeError):
+    pass
+
+
+class RowMap(ctypes.Structure):
+    _fields_ = [("rows_per_batch", ctypes.c_int64), ("batch_stride", ctypes.c_int64), ("row_stride", ctypes.c_int64)]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64),
+                ("A", ctypes.c_void_p), ("a_map", RowMap), ("a_nseg", ctypes.c_int64),
+                ("a_seg_len", ctypes.c_int64), ("a_seg_stride", ctypes.c_int64),
+                ("W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
+                ("bias", ctypes.c_void_p),
+                ("R", ctypes.c_void_p), ("r_map", RowMap), ("r_dtype", ctypes.c_int),
+                ("C", ctypes.c_void_p), ("c_map", RowMap), ("c_dtype", ctypes.c_int),
+                ("ab_dtype", ctypes.c_int), ("act", ctypes.c_int), ("alpha", ctypes.c_float),
+                ("n_groups", ctypes.c_int64), ("a_group_stride", ctypes.c_int64),
+                ("w_group_stride", ctypes.c_int64), ("c_group_stride", ctypes.c_int64)]
+
+
+_SCALARS = [("uint64_t", ctypes.c_uint64), ("int64_t", ctypes.c_int64), ("int32_t", ctypes.c_int32),
+            ("double", ctypes.c_double), ("float", ctypes.c_float), ("int", ctypes.c_int)]
+
+
+def parse_header(path=HEADER_PATH):
+    """Returns {name: (restype, [argtypes])} for every function the header declares."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"typedef\s+struct.*?}\s*\w+\s*;", " ", src, flags=re.S)
+    src = re.sub(r"enum\s+\w+\s*{.*?}\s*;", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(occ_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                    continue
+                for key, ct in _SCALARS:
+                    if re.search(r"\b%s\b" % key, a):
+                        argtypes.append(ct)
+                        break
+                else:
+                    raise OccError("cannot map C argument %r of %s" % (a, name))
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises OccError when it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OccError("libocc_hip.so is missing at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` or `make -C occm_amd/csrc`.  occm_amd has no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(handle, name)          # AttributeError -> header/library mismatch, surfaces loudly
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().occ_last_error()
+        raise OccError("%s failed (%d): %s" % (what or "libocc_hip call", rc, msg.decode() if msg else "?"))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise OccError("occm_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False and there is no CPU fallback")
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device (or host, for *_host arguments) pointer of a contiguous tensor / numpy array, or NULL."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if hasattr(t, "data_ptr"):
+        return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.ctypes.data)
+
+
+def dtype_code(t):
+    import torch
+    return {torch.float32: OCC_F32, torch.bfloat16: OCC_BF16, torch.float64: OCC_F64}[t.dtype]

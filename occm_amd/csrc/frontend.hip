@@ -1,0 +1,285 @@
+// Row kernels of the wav2vec2 / XLS-R front-end (fairseq Wav2Vec2Model reached from
+// models/sslassist.py:48, models/xlsr.py:46): LayerNorm(+GELU), the first conv block fused with its
+// LayerNorm and GELU, and the self-attention core.
+#include "occ_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over rows of width C (C % 8 == 0, C <= 2048): one wave per row, the row lives in
+// registers, mean and variance are two exact passes over those registers, 16-byte accesses.
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<unsigned short> {
+    static __device__ __forceinline__ void load(const unsigned short* p, float (&v)[8]) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(unsigned short* p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+template <typename TI, typename TO, int NIT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, TO* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, long long rows, int C, float eps, int gelu) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const TI* xr = x + row * C;
+    float v[NIT][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = (it * 64 + lane) * 8;
+        if (c < C) {
+            Vec8<TI>::load(xr + c, v[it]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[it][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = (it * 64 + lane) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[it][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    TO* yr = y + row * C;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = (it * 64 + lane) * 8;
+        if (c < C) {
+            float g[8], b[8], o[8];
+            Vec8<float>::load(gamma + c, g);
+            Vec8<float>::load(beta + c, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (v[it][e] - mean) * rstd * g[e] + b[e];
+                o[e] = gelu ? gelu_erf(t) : t;
+            }
+            Vec8<TO>::store(yr + c, o);
+        }
+    }
+}
+
+template <typename TI, typename TO>
+int launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, long long rows, int C, float eps, int gelu, hipStream_t s) {
+    const dim3 grid((unsigned)occ_cdiv(rows, 4)), block(256);
+    const int nit = (C + 511) / 512;
+    switch (nit) {
+        case 1: hipLaunchKernelGGL((layernorm_kernel<TI, TO, 1>), grid, block, 0, s, (const TI*)x, (TO*)y, gamma, beta, rows, C, eps, gelu); break;
+        case 2: hipLaunchKernelGGL((layernorm_kernel<TI, TO, 2>), grid, block, 0, s, (const TI*)x, (TO*)y, gamma, beta, rows, C, eps, gelu); break;
+        case 3: hipLaunchKernelGGL((layernorm_kernel<TI, TO, 3>), grid, block, 0, s, (const TI*)x, (TO*)y, gamma, beta, rows, C, eps, gelu); break;
+        case 4: hipLaunchKernelGGL((layernorm_kernel<TI, TO, 4>), grid, block, 0, s, (const TI*)x, (TO*)y, gamma, beta, rows, C, eps, gelu); break;
+        default: return -1;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// First conv block: Conv1d(1 -> 512, k, stride) + bias -> LayerNorm(512) -> GELU, channels-last out.
+// One wave per output frame; lane owns 8 channels whose k taps stay in registers; the waveform tile
+// (256 frames * stride + k samples) is staged once per workgroup in LDS and read back as broadcasts.
+constexpr int C0_FRAMES = 256;     // frames per workgroup (64 per wave)
+constexpr int C0_MAXK = 16;
+
+template <typename TO>
+__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ wav, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, TO* __restrict__ out,
+                                                           int L, int Tout, int k, int stride, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float smp[];
+    const int b = blockIdx.y, f0 = blockIdx.x * C0_FRAMES;
+    const int nsamp = (C0_FRAMES - 1) * stride + k;
+    const float* wb = wav + (size_t)b * L;
+    for (int i = threadIdx.x; i < nsamp; i += 256) {
+        const int g = f0 * stride + i;
+        smp[i] = g < L ? wb[g] : 0.f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = lane * 8;
+    float wr[8][C0_MAXK], br[8], gr[8], ber[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        br[e] = bias[c0 + e]; gr[e] = gamma[c0 + e]; ber[e] = beta[c0 + e];
+#pragma unroll
+        for (int t = 0; t < C0_MAXK; ++t) wr[e][t] = t < k ? w[(size_t)(c0 + e) * k + t] : 0.f;
+    }
+    __syncthreads();
+    for (int fi = 0; fi < C0_FRAMES / 4; ++fi) {
+        const int fl = wave * (C0_FRAMES / 4) + fi;
+        const int f = f0 + fl;
+        if (f >= Tout) break;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = br[e];
+#pragma unroll
+        for (int t = 0; t < C0_MAXK; ++t) {
+            if (t < k) {
+                const float xv = smp[fl * stride + t];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(wr[e][t], xv, acc[e]);
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += acc[e];
+        const float mean = wave_sum(s) * (1.0f / 512.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = acc[e] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 512.0f) + eps);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = gelu_erf((acc[e] - mean) * rstd * gr[e] + ber[e]);
+        Vec8<TO>::store(out + ((size_t)b * Tout + f) * 512 + c0, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Self-attention core, f32 arithmetic, storage type T (f32 or bf16): softmax(scale * Q.K^T).V per
+// (batch, head).  K and V of one head are staged in LDS as f32 (rows padded to hd+1 floats so the
+// key-per-lane reads are conflict-free); each wave walks query rows: lanes = keys for the scores,
+// lanes = head dims for the weighted sum.  Short sequences only (T*(hd+1)*8 + ... <= 160 KiB).
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H, int hd,
+                                                       long long ld_qkv, long long ld_out, float scale, int qsplit) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = H * hd;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int hp = hd + 1;
+    float* Ks = sm;                       // [Tn][hd+1]
+    float* Vs = Ks + (size_t)Tn * hp;     // [Tn][hd+1]
+    float* Ps = Vs + (size_t)Tn * hp;     // [4 waves][Tn]
+    float* Qs = Ps + 4 * Tn;              // [4 waves][hd]
+    const T* base = qkv + (size_t)b * Tn * ld_qkv + (size_t)h * hd;
+    for (int i = threadIdx.x; i < Tn * hd; i += 256) {
+        const int t = i / hd, d = i - t * hd;
+        Ks[t * hp + d] = occ_load_f32(base + (size_t)t * ld_qkv + D + d);
+        Vs[t * hp + d] = occ_load_f32(base + (size_t)t * ld_qkv + 2 * D + d);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* pw = Ps + wave * Tn;
+    float* qw = Qs + wave * hd;
+    const int rows_per = (Tn + qsplit - 1) / qsplit;
+    const int q_begin = blockIdx.y * rows_per, q_end = min(Tn, q_begin + rows_per);
+    const int nkey = (Tn + 63) / 64;
+    for (int qi = q_begin + wave; qi < q_end; qi += 4) {
+        for (int d = lane; d < hd; d += 64) qw[d] = occ_load_f32(base + (size_t)qi * ld_qkv + d) * scale;
+        __builtin_amdgcn_wave_barrier();
+        float mx = -3.0e38f;
+#pragma unroll 4
+        for (int kb = 0; kb < nkey; ++kb) {
+            const int key = kb * 64 + lane;
+            float s = -3.0e38f;
+            if (key < Tn) {
+                s = 0.f;
+                const float* kr = Ks + key * hp;
+                for (int d = 0; d < hd; ++d) s = fmaf(qw[d], kr[d], s);
+            }
+            mx = fmaxf(mx, s);
+            if (key < Tn) pw[key] = s;
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int kb = 0; kb < nkey; ++kb) {
+            const int key = kb * 64 + lane;
+            if (key < Tn) { const float p = expf(pw[key] - mx); pw[key] = p; sum += p; }
+        }
+        sum = wave_sum(sum);
+        __builtin_amdgcn_wave_barrier();
+        const float inv = 1.0f / sum;
+        for (int d = lane; d < hd; d += 64) {
+            float o = 0.f;
+            for (int key = 0; key < Tn; ++key) o = fmaf(pw[key], Vs[key * hp + d], o);
+            occ_store_f32(out + ((size_t)b * Tn + qi) * ld_out + (size_t)h * hd + d, o * inv);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int occ_layernorm(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int64_t rows, int64_t C,
+                  float eps, int gelu, void* stream) {
+    OCC_CHECK_ARG(x && y && gamma && beta, "occ_layernorm: null pointer");
+    OCC_CHECK_ARG(rows >= 1 && C >= 8 && C % 8 == 0 && C <= 2048, "occ_layernorm: C must be a multiple of 8 in [8,2048] (C=%ld)", (long)C);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = -1;
+    if (x_dtype == OCC_F32 && y_dtype == OCC_F32) rc = launch_layernorm<float, float>(x, y, gamma, beta, rows, (int)C, eps, gelu, s);
+    else if (x_dtype == OCC_F32 && y_dtype == OCC_BF16) rc = launch_layernorm<float, unsigned short>(x, y, gamma, beta, rows, (int)C, eps, gelu, s);
+    else if (x_dtype == OCC_BF16 && y_dtype == OCC_BF16) rc = launch_layernorm<unsigned short, unsigned short>(x, y, gamma, beta, rows, (int)C, eps, gelu, s);
+    else if (x_dtype == OCC_BF16 && y_dtype == OCC_F32) rc = launch_layernorm<unsigned short, float>(x, y, gamma, beta, rows, (int)C, eps, gelu, s);
+    if (rc != 0) { occ_set_error("occ_layernorm: unsupported dtype pair %d -> %d", x_dtype, y_dtype); return OCC_EUNSUPPORTED; }
+    OCC_LAUNCH_CHECK("occ_layernorm");
+    return OCC_OK;
+}
+
+int occ_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta, void* out, int out_dtype,
+                      int64_t B, int64_t L, int64_t Tout, int64_t C, int64_t k, int64_t stride, float eps, void* stream) {
+    OCC_CHECK_ARG(wav && w && bias && gamma && beta && out, "occ_conv0_ln_gelu: null pointer");
+    OCC_CHECK_ARG(C == 512, "occ_conv0_ln_gelu: C must be 512 (got %ld)", (long)C);
+    OCC_CHECK_ARG(k >= 1 && k <= C0_MAXK && stride >= 1 && stride <= 16, "occ_conv0_ln_gelu: k in [1,16], stride in [1,16]");
+    OCC_CHECK_ARG(B >= 1 && B < 65536 && L >= k && Tout == (L - k) / stride + 1, "occ_conv0_ln_gelu: Tout must equal (L-k)/stride+1");
+    const dim3 grid((unsigned)occ_cdiv(Tout, C0_FRAMES), (unsigned)B), block(256);
+    const size_t shm = ((C0_FRAMES - 1) * stride + k) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == OCC_F32)
+        hipLaunchKernelGGL(conv0_ln_gelu_kernel<float>, grid, block, shm, s, wav, w, bias, gamma, beta, (float*)out, (int)L, (int)Tout, (int)k, (int)stride, eps);
+    else if (out_dtype == OCC_BF16)
+        hipLaunchKernelGGL(conv0_ln_gelu_kernel<unsigned short>, grid, block, shm, s, wav, w, bias, gamma, beta, (unsigned short*)out, (int)L, (int)Tout, (int)k, (int)stride, eps);
+    else { occ_set_error("occ_conv0_ln_gelu: out dtype must be f32 or bf16"); return OCC_EUNSUPPORTED; }
+    OCC_LAUNCH_CHECK("occ_conv0_ln_gelu");
+    return OCC_OK;
+}
+
+int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd, int64_t ld_qkv, int64_t ld_out,
+                  float scale, void* stream) {
+    OCC_CHECK_ARG(qkv && out, "occ_attention: null pointer");
+    OCC_CHECK_ARG(B >= 1 && T >= 1 && H >= 1 && hd >= 8 && hd <= 128, "occ_attention: bad shape");
+    OCC_CHECK_ARG(T <= 1024, "occ_attention: T=%ld exceeds the short-sequence limit 1024", (long)T);
+    OCC_CHECK_ARG(ld_qkv >= 3 * H * hd && ld_out >= H * hd, "occ_attention: leading dimensions too small");
+    const size_t shm = ((size_t)2 * T * (hd + 1) + 4 * T + 4 * hd) * sizeof(float);
+    OCC_CHECK_ARG(shm <= 160 * 1024, "occ_attention: T=%ld hd=%ld needs %zu B of LDS (> 160 KiB)", (long)T, (long)hd, shm);
+    const int qsplit = 4;
+    const dim3 grid((unsigned)(B * H), qsplit), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (dtype == OCC_F32) {
+        e = hipFuncSetAttribute((const void*)attention_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) { occ_set_error("occ_attention: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+        hipLaunchKernelGGL(attention_kernel<float>, grid, block, shm, s, (const float*)qkv, (float*)out, (int)T, (int)H, (int)hd, (long long)ld_qkv, (long long)ld_out, scale, qsplit);
+    } else if (dtype == OCC_BF16) {
+        e = hipFuncSetAttribute((const void*)attention_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) { occ_set_error("occ_attention: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+        hipLaunchKernelGGL(attention_kernel<unsigned short>, grid, block, shm, s, (const unsigned short*)qkv, (unsigned short*)out, (int)T, (int)H, (int)hd, (long long)ld_qkv, (long long)ld_out, scale, qsplit);
+    } else { occ_set_error("occ_attention: dtype must be f32 or bf16"); return OCC_EUNSUPPORTED; }
+    OCC_LAUNCH_CHECK("occ_attention");
+    return OCC_OK;
+}
+
+}  // extern "C"

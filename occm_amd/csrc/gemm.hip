@@ -1,0 +1,249 @@
+// MFMA GEMM family for gfx950:  C = act(alpha * X.W^T + bias) + R
+//   X: [M,K] activations addressed through an occ_rowmap (+ optional K-segments), K contiguous
+//   W: [N,K] weights in torch Linear layout, K contiguous
+// Every nn.Linear and Conv1d of the wav2vec2 front-end (reached from sslassist.py:48) and the Linear /
+// 1x1-conv layers of the AASIST back-end (sslassist.py:448-471) map onto this kernel.
+//
+// Tiling (per workgroup of 4 waves): 128(m) x 128(n) output tile, 128-byte K slabs (64 bf16 / 32 f32),
+// double-buffered in LDS (2 x 2 x 16 KiB), register-staged global->LDS copies issued one slab ahead,
+// XOR-swizzled 16-byte chunks so the ds_read_b128 fragment reads spread over the banks.  Each wave
+// owns a 64x64 sub-tile as 4x4 MFMA 16x16 blocks.  The MFMA is issued with W as the A operand and X as
+// the B operand, so a lane ends up with 4 consecutive n of one output row m: bias/residual loads and
+// the C store are 8/16-byte vector accesses.
+// bf16 inputs use v_mfma_f32_16x16x32_bf16 (f32 accumulate); f32 inputs use the exact-f32
+// v_mfma_f32_16x16x4_f32 with the k index permuted identically on both operands.
+#include "occ_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int TM = 128, TN = 128, THREADS = 256;
+constexpr int SLAB_BYTES = 128;                 // K bytes per row per slab
+constexpr int CHUNKS = SLAB_BYTES / 16;         // 8 chunks of 16 B per row
+
+struct RowMapI { long long rpb, bstride, rstride; };
+
+struct GemmArgs {
+    long long M, N, K;
+    const char* X; RowMapI xmap; long long nseg, seg_len, seg_stride;
+    const char* W; long long ldw;
+    const float* bias;
+    const char* R; RowMapI rmap; int r_dtype;
+    char* C; RowMapI cmap; int c_dtype;
+    int act; float alpha;
+    int nbm, nbn;
+    long long a_gstride, w_gstride, c_gstride;
+};
+
+__device__ __forceinline__ long long row_off(const RowMapI& m, long long row) {
+    const long long b = row / m.rpb;
+    return b * m.bstride + (row - b * m.rpb) * m.rstride;
+}
+
+__device__ __forceinline__ float act_rt(int act, float v) {
+    switch (act) {
+        case OCC_ACT_GELU: return gelu_erf(v);
+        case OCC_ACT_SELU: return selu_f(v);
+        case OCC_ACT_RELU: return v > 0.f ? v : 0.f;
+        case OCC_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
+    constexpr int ES = BF16 ? 2 : 4;            // element size
+    constexpr int CE = 16 / ES;                 // elements per 16-B chunk
+    constexpr int SLAB_K = SLAB_BYTES / ES;     // K elements per slab
+    __shared__ uint4 lds[2][2][TM * CHUNKS];    // [buffer][X|W][row*8 + swizzled chunk]
+
+    // ---- XCD-aware tile id: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
+    // range of tiles so neighbouring tiles re-use the same X / W panels out of that L2.
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    const long long m0 = (long long)tile_m * TM, n0 = (long long)tile_n * TN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const long long grp = blockIdx.y;
+    const char* Xg = a.X + grp * a.a_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const long long cshift = grp * a.c_gstride;      // column shift of C / R / bias for this group
+
+    // ---- staging assignment: this thread copies chunk `ch` of rows (tid>>3) + 32*i
+    const int ch = tid & 7, srow = tid >> 3;
+    long long xoff[4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long long m = m0 + srow + 32 * i; if (m > a.M - 1) m = a.M - 1;
+        long long n = n0 + srow + 32 * i; if (n > a.N - 1) n = a.N - 1;
+        xoff[i] = row_off(a.xmap, m) * ES;
+        woff[i] = n * a.ldw * ES;
+    }
+    const int nslab = (int)((a.K + SLAB_K - 1) / SLAB_K);
+
+    uint4 px[4], pw[4];
+    auto issue_loads = [&](int slab) {
+        const long long k0 = (long long)slab * SLAB_K + ch * CE;
+        long long kx = k0;
+        if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
+        const bool ok = k0 < a.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            px[i] = ok ? *reinterpret_cast<const uint4*>(Xg + xoff[i] + kx * ES) : make_uint4(0, 0, 0, 0);
+            pw[i] = ok ? *reinterpret_cast<const uint4*>(Wg + woff[i] + k0 * ES) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto write_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 32 * i;
+            const int idx = row * CHUNKS + (ch ^ (row & 7));
+            lds[buf][0][idx] = px[i];
+            lds[buf][1][idx] = pw[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue_loads(0);
+    write_lds(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int slab = 0; slab < nslab; ++slab) {
+        const int cur = slab & 1;
+        if (slab + 1 < nslab) issue_loads(slab + 1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 wf[4], xf[4];
+            const int chk = kb * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = wn * 64 + i * 16 + fr;
+                wf[i] = lds[cur][1][rw * CHUNKS + (chk ^ (rw & 7))];
+                const int rx = wm * 64 + i * 16 + fr;
+                xf[i] = lds[cur][0][rx * CHUNKS + (chk ^ (rx & 7))];
+            }
+            if constexpr (BF16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+            } else {
+                // lane group fq holds k = 4*fq + e of this 16-k block; step e multiplies k in {e, 4+e, 8+e, 12+e}
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                reinterpret_cast<const float*>(&wf[i])[e], reinterpret_cast<const float*>(&xf[j])[e], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (slab + 1 < nslab) write_lds(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long m = m0 + wm * 64 + j * 16 + fr;
+        if (m >= a.M) continue;
+        const long long coff = row_off(a.cmap, m) + cshift;
+        const long long roff = a.R ? row_off(a.rmap, m) + cshift : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long n = n0 + wn * 64 + i * 16 + fq * 4;
+            if (n >= a.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * a.alpha;
+            if (a.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + cshift + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            if (a.act != OCC_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_rt(a.act, v[e]);
+            }
+            if (a.R) {
+                if (a.r_dtype == OCC_F32) {
+                    const float4 rv = *reinterpret_cast<const float4*>(a.R + (roff + n) * 4);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                } else {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(a.R + (roff + n) * 2);
+                    v[0] += bf16_bits_to_f32((unsigned short)(rv.x & 0xffff)); v[1] += bf16_bits_to_f32((unsigned short)(rv.x >> 16));
+                    v[2] += bf16_bits_to_f32((unsigned short)(rv.y & 0xffff)); v[3] += bf16_bits_to_f32((unsigned short)(rv.y >> 16));
+                }
+            }
+            if (a.c_dtype == OCC_F32) {
+                *reinterpret_cast<float4*>(a.C + (coff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2*>(a.C + (coff + n) * 2) = o;
+            }
+        }
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
+    OCC_CHECK_ARG(d, "occ_gemm: null descriptor");
+    OCC_CHECK_ARG(d->A && d->W && d->C, "occ_gemm: null operand");
+    OCC_CHECK_ARG(d->M >= 1 && d->N >= 1 && d->K >= 1, "occ_gemm: bad shape M=%ld N=%ld K=%ld", (long)d->M, (long)d->N, (long)d->K);
+    OCC_CHECK_ARG(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_F32, "occ_gemm: ab_dtype must be bf16 or f32");
+    OCC_CHECK_ARG(d->c_dtype == OCC_BF16 || d->c_dtype == OCC_F32, "occ_gemm: c_dtype must be bf16 or f32");
+    OCC_CHECK_ARG(!d->R || d->r_dtype == OCC_BF16 || d->r_dtype == OCC_F32, "occ_gemm: r_dtype must be bf16 or f32");
+    const int es = d->ab_dtype == OCC_BF16 ? 2 : 4;
+    const int ce = 16 / es;
+    OCC_CHECK_ARG(d->K % ce == 0 && d->N % 4 == 0, "occ_gemm: needs K %% %d == 0 and N %% 4 == 0 (K=%ld N=%ld)", ce, (long)d->K, (long)d->N);
+    const long long nseg = d->a_nseg > 1 ? d->a_nseg : 1;
+    const long long seg_len = nseg > 1 ? d->a_seg_len : d->K;
+    OCC_CHECK_ARG(nseg * seg_len == d->K, "occ_gemm: a_nseg*a_seg_len != K");
+    OCC_CHECK_ARG(seg_len % ce == 0 && (nseg == 1 || d->a_seg_stride % ce == 0), "occ_gemm: K segments must be 16-byte granular");
+    OCC_CHECK_ARG(d->a_map.rows_per_batch >= 1 && d->c_map.rows_per_batch >= 1, "occ_gemm: rows_per_batch must be >= 1");
+    OCC_CHECK_ARG(d->a_map.row_stride % ce == 0 && d->a_map.batch_stride % ce == 0 && d->ldw % ce == 0 && d->ldw >= d->K,
+                  "occ_gemm: A/W strides must keep rows 16-byte aligned");
+    OCC_CHECK_ARG(d->c_map.row_stride % 4 == 0 && d->c_map.batch_stride % 4 == 0, "occ_gemm: C strides must be multiples of 4 elements");
+    OCC_CHECK_ARG(aligned16(d->A) && aligned16(d->W) && aligned16(d->C) && (!d->bias || aligned16(d->bias)) && (!d->R || aligned16(d->R)),
+                  "occ_gemm: operands must be 16-byte aligned");
+    if (d->R) OCC_CHECK_ARG(d->r_map.rows_per_batch >= 1 && d->r_map.row_stride % 4 == 0 && d->r_map.batch_stride % 4 == 0, "occ_gemm: bad residual map");
+    GemmArgs a;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.X = (const char*)d->A; a.xmap = {d->a_map.rows_per_batch, d->a_map.batch_stride, d->a_map.row_stride};
+    a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->a_seg_stride;
+    a.W = (const char*)d->W; a.ldw = d->ldw;
+    a.bias = (const float*)d->bias;
+    a.R = (const char*)d->R; a.rmap = {d->r_map.rows_per_batch, d->r_map.batch_stride, d->r_map.row_stride}; a.r_dtype = d->r_dtype;
+    a.C = (char*)d->C; a.cmap = {d->c_map.rows_per_batch, d->c_map.batch_stride, d->c_map.row_stride}; a.c_dtype = d->c_dtype;
+    a.act = d->act; a.alpha = d->alpha;
+    a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
+    const long long ng = d->n_groups > 1 ? d->n_groups : 1;
+    a.a_gstride = ng > 1 ? d->a_group_stride : 0; a.w_gstride = ng > 1 ? d->w_group_stride : 0; a.c_gstride = ng > 1 ? d->c_group_stride : 0;
+    OCC_CHECK_ARG(ng < 65536 && a.a_gstride % ce == 0 && a.w_gstride % ce == 0 && a.c_gstride % 4 == 0, "occ_gemm: bad group strides");
+    const long long total = (long long)a.nbm * a.nbn;
+    OCC_CHECK_ARG(total < (1ll << 30), "occ_gemm: too many tiles");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<true>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL(gemm_kernel<false>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    OCC_LAUNCH_CHECK("occ_gemm");
+    return OCC_OK;
+}

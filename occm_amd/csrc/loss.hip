@@ -1,0 +1,168 @@
+// One-class losses, distance scoring and the Adam step.
+// Reference: losses/custom_loss.py:4-29, 78-99; oc_classifier.py:193, 261; oc_training.py:324, 385.
+#include "occ_common.h"
+
+namespace {
+
+constexpr int LOSS_THREADS = 256;
+constexpr float PAIR_EPS = 1e-6f;       // F.pairwise_distance eps, added to the difference
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x / OCC_WAVE, l = threadIdx.x % OCC_WAVE;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// One workgroup; groups are walked in order so the sum is reproducible.
+__global__ __launch_bounds__(LOSS_THREADS) void compactness_kernel(const float* __restrict__ emb, float* __restrict__ loss,
+                                                                  float* __restrict__ demb, int n_groups, int group, int E, float scale) {
+    __shared__ float red[4];
+    __shared__ float inv_dist[6];
+    const int NB = 6;                                    // custom_loss.py:15
+    float total = 0.f;
+    for (int g = 0; g < n_groups; ++g) {
+        const float* e = emb + (size_t)g * group * E;
+        float d2[NB] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = threadIdx.x; c < E; c += LOSS_THREADS) {
+            float v[NB], S = 0.f;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) { v[i] = e[(size_t)i * E + c]; S += v[i]; }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const float u = v[i] - (S - v[i]) / (float)(NB - 1) + PAIR_EPS;
+                d2[i] += u * u;
+            }
+        }
+        float gl = 0.f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float dist = sqrtf(block_sum_256(d2[i], red));
+            gl += dist;
+            if (threadIdx.x == 0) inv_dist[i] = dist > 0.f ? 1.f / dist : 0.f;
+        }
+        total += gl / (float)NB;
+        if (demb) {
+            __syncthreads();
+            float* de = demb + (size_t)g * group * E;
+            const float k = scale / ((float)NB * (float)n_groups);
+            for (int c = threadIdx.x; c < E; c += LOSS_THREADS) {
+                float v[NB], S = 0.f, uh[NB], uh_sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) { v[i] = e[(size_t)i * E + c]; S += v[i]; }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    uh[i] = (v[i] - (S - v[i]) / (float)(NB - 1) + PAIR_EPS) * inv_dist[i];
+                    uh_sum += uh[i];
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    de[(size_t)i * E + c] = k * ((float)NB / (float)(NB - 1) * uh[i] - uh_sum / (float)(NB - 1));
+                for (int i = NB; i < group; ++i) de[(size_t)i * E + c] = 0.f;
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) loss[0] = total / (float)n_groups;
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                         float* __restrict__ loss, float* __restrict__ dlogits, int B, int C, float scale) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < B; r += LOSS_THREADS) {
+        const float* x = logits + (size_t)r * C;
+        float m = x[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+        const float lse = m + logf(s);
+        const int y = (int)labels[r];
+        acc += lse - x[y];
+        if (dlogits)
+            for (int c = 0; c < C; ++c)
+                dlogits[(size_t)r * C + c] = (expf(x[c] - lse) - (c == y ? 1.f : 0.f)) * scale / (float)B;
+    }
+    const float tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) loss[0] = tot / (float)B;       // custom_loss.py:99: sum / len
+}
+
+__global__ void pairwise_dist_kernel(const float* __restrict__ ref, const float* __restrict__ emb, float* __restrict__ dist, int N, int E) {
+    const int row = blockIdx.x * (blockDim.x / OCC_WAVE) + threadIdx.x / OCC_WAVE;
+    const int lane = threadIdx.x % OCC_WAVE;
+    if (row >= N) return;
+    float s = 0.f;
+    for (int c = lane; c < E; c += OCC_WAVE) {
+        const float d = ref[c] - emb[(size_t)row * E + c] + PAIR_EPS;
+        s += d * d;
+    }
+    s = wave_sum(s);
+    if (lane == 0) dist[row] = sqrtf(s);
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(void* const* __restrict__ params, void* const* __restrict__ grads,
+                                                         void* const* __restrict__ m1, void* const* __restrict__ m2,
+                                                         const int64_t* __restrict__ sizes, float lr, float b1, float b2, float eps,
+                                                         float bc1, float bc2_sqrt, float gscale) {
+    const int t = blockIdx.y;
+    const int64_t n = sizes[t];
+    float* p = (float*)params[t];
+    const float* g = (const float*)grads[t];
+    float* m = (float*)m1[t];
+    float* v = (float*)m2[t];
+    if (g == nullptr) return;                              // parameter without gradient (dead bn1, quirk 1)
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = m[i] * b1 + (1.f - b1) * gi;       // exp_avg.lerp_(grad, 1-beta1)
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int occ_compactness_loss(const float* emb, float* loss, float* demb, int64_t n_groups, int64_t group, int64_t E, float scale, void* stream) {
+    OCC_CHECK_ARG(emb && loss, "occ_compactness_loss: null pointer");
+    OCC_CHECK_ARG(n_groups >= 1 && group >= 6 && E >= 1, "occ_compactness_loss: needs n_groups>=1, group>=6 (got %ld, %ld)", (long)n_groups, (long)group);
+    hipLaunchKernelGGL(compactness_kernel, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, emb, loss, demb, (int)n_groups, (int)group, (int)E, scale);
+    OCC_LAUNCH_CHECK("occ_compactness_loss");
+    return OCC_OK;
+}
+
+int occ_ce_loss(const float* logits, const int64_t* labels, float* loss, float* dlogits, int64_t B, int64_t C, float scale, void* stream) {
+    OCC_CHECK_ARG(logits && labels && loss, "occ_ce_loss: null pointer");
+    OCC_CHECK_ARG(B >= 1 && C >= 2 && C <= 1024, "occ_ce_loss: bad shape");
+    hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, logits, labels, loss, dlogits, (int)B, (int)C, scale);
+    OCC_LAUNCH_CHECK("occ_ce_loss");
+    return OCC_OK;
+}
+
+int occ_pairwise_dist(const float* ref, const float* emb, float* dist, int64_t N, int64_t E, void* stream) {
+    OCC_CHECK_ARG(ref && emb && dist && N >= 1 && E >= 1, "occ_pairwise_dist: bad argument");
+    hipLaunchKernelGGL(pairwise_dist_kernel, dim3((unsigned)occ_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, ref, emb, dist, (int)N, (int)E);
+    OCC_LAUNCH_CHECK("occ_pairwise_dist");
+    return OCC_OK;
+}
+
+int occ_adam_multi(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq, const int64_t* sizes,
+                   int64_t n_tensors, int64_t max_size, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale, void* stream) {
+    OCC_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && sizes, "occ_adam_multi: null pointer");
+    OCC_CHECK_ARG(n_tensors >= 1 && n_tensors < 65536 && step >= 1 && max_size >= 1, "occ_adam_multi: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    int64_t bx = occ_cdiv(max_size, 256 * 4);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, sizes, lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+    OCC_LAUNCH_CHECK("occ_adam_multi");
+    return OCC_OK;
+}
+
+}  // extern "C"

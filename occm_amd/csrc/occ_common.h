@@ -1,0 +1,83 @@
+// Shared helpers for the libocc_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/occ_hip.h"
+
+#define OCC_WAVE 64
+
+void occ_set_error(const char* fmt, ...);
+
+#define OCC_CHECK_ARG(cond, ...)                         \
+    do {                                                 \
+        if (!(cond)) {                                   \
+            occ_set_error(__VA_ARGS__);                  \
+            return OCC_EINVAL;                           \
+        }                                                \
+    } while (0)
+
+#define OCC_LAUNCH_CHECK(name)                                                   \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            occ_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return OCC_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+typedef __hip_bfloat16 bf16_t;
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned)b) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    // plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+    bf16_t h = __float2bfloat16(f);
+    return *reinterpret_cast<unsigned short*>(&h);
+}
+
+template <typename T> __device__ __forceinline__ float occ_load_f32(const T* p);
+template <> __device__ __forceinline__ float occ_load_f32<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float occ_load_f32<unsigned short>(const unsigned short* p) { return bf16_bits_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void occ_store_f32(T* p, float v);
+template <> __device__ __forceinline__ void occ_store_f32<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void occ_store_f32<unsigned short>(unsigned short* p, float v) { *p = f32_to_bf16_bits(v); }
+
+// ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T u = __shfl_xor(v, o, 64); v = u < v ? u : v; }
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float selu_f(float x) {
+    const float a = 1.6732632423543772848170429916717f, s = 1.0507009873554804934193349852946f;
+    return x > 0.f ? s * x : s * a * (expf(x) - 1.0f);
+}
+__device__ __forceinline__ float selu_grad_from_in(float x) {
+    const float a = 1.6732632423543772848170429916717f, s = 1.0507009873554804934193349852946f;
+    return x > 0.f ? s : s * a * expf(x);
+}
+
+template <int ACT> __device__ __forceinline__ float occ_apply_act(float x) {
+    if (ACT == OCC_ACT_GELU) return gelu_erf(x);
+    if (ACT == OCC_ACT_SELU) return selu_f(x);
+    if (ACT == OCC_ACT_RELU) return x > 0.f ? x : 0.f;
+    if (ACT == OCC_ACT_TANH) return tanhf(x);
+    return x;
+}
+
+static inline int64_t occ_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,226 @@
+"""Thin torch-tensor wrappers over the C ABI of libocc_hip.so (pointers + sizes in, nothing else).
+
+torch is used for device memory and streams only; every function here enqueues hand-written HIP
+kernels on the current stream and raises ``OccError`` on failure.  There is no fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, OCC_BF16, OCC_F32, OCC_F64,  # noqa: F401
+                   GemmDesc, RowMap, check, dtype_code, lib, ptr, stream_ptr)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.OccError("occm_amd ops need CUDA/HIP tensors (got a %s tensor); there is no CPU path" % t.device)
+    return t
+
+
+def rowmap(rows_per_batch, batch_stride, row_stride):
+    return RowMap(int(rows_per_batch), int(batch_stride), int(row_stride))
+
+
+def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, act=ACT_NONE, alpha=1.0,
+             R=None, r_map=None, r_dtype=OCC_F32, a_seg=None, groups=None):
+    """Direct descriptor-level call.  A/W/C/R/bias are ints (device addresses) or tensors."""
+    d = GemmDesc()
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.A = A if isinstance(A, int) else A.data_ptr()
+    d.a_map = a_map
+    if a_seg is not None:
+        d.a_nseg, d.a_seg_len, d.a_seg_stride = [int(v) for v in a_seg]
+    else:
+        d.a_nseg, d.a_seg_len, d.a_seg_stride = 1, int(K), 0
+    d.W = W if isinstance(W, int) else W.data_ptr()
+    d.ldw = int(ldw)
+    d.bias = None if bias is None else (bias if isinstance(bias, int) else bias.data_ptr())
+    if R is not None:
+        d.R = R if isinstance(R, int) else R.data_ptr()
+        d.r_map = r_map
+        d.r_dtype = r_dtype
+    d.C = C if isinstance(C, int) else C.data_ptr()
+    d.c_map = c_map
+    d.c_dtype = c_dtype
+    d.ab_dtype = ab_dtype
+    d.act = act
+    d.alpha = float(alpha)
+    if groups is not None:
+        d.n_groups, d.a_group_stride, d.w_group_stride, d.c_group_stride = [int(v) for v in groups]
+    check(lib().occ_gemm(ctypes.byref(d), stream_ptr()), "occ_gemm")
+
+
+def linear(x, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, alpha=1.0):
+    """y = act(alpha * x @ w.T + bias) + residual for 2-D row-major x [M,K], w [N,K]."""
+    _dev(x); _dev(w)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.dtype == w.dtype and x.is_contiguous() and w.is_contiguous()
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=out_dtype or x.dtype)
+    full = rowmap(M, 0, K)
+    gemm_raw(M, N, K, x, full, w, K, out, rowmap(M, 0, N), dtype_code(out), dtype_code(x), bias=bias, act=act, alpha=alpha,
+             R=residual, r_map=None if residual is None else rowmap(M, 0, N),
+             r_dtype=OCC_F32 if residual is None else dtype_code(residual))
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, gelu=False, out=None, out_dtype=None):
+    _dev(x)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
+    check(lib().occ_layernorm(ptr(x), dtype_code(x), ptr(out), dtype_code(out), ptr(gamma), ptr(beta), rows, C, eps, int(gelu), stream_ptr()),
+          "occ_layernorm")
+    return out
+
+
+def conv0_ln_gelu(wav, w, bias, gamma, beta, k, stride, out_dtype, eps=1e-5, out=None):
+    _dev(wav)
+    B, L = wav.shape
+    Tout = (L - k) // stride + 1
+    if out is None:
+        out = torch.empty(B, Tout, 512, device=wav.device, dtype=out_dtype)
+    check(lib().occ_conv0_ln_gelu(ptr(wav), ptr(w), ptr(bias), ptr(gamma), ptr(beta), ptr(out), dtype_code(out), B, L, Tout, 512, k, stride, eps,
+                                  stream_ptr()), "occ_conv0_ln_gelu")
+    return out
+
+
+def attention(qkv, B, T, H, hd, scale, out=None):
+    _dev(qkv)
+    D = H * hd
+    assert qkv.shape == (B * T, 3 * D) and qkv.is_contiguous()
+    if out is None:
+        out = torch.empty(B * T, D, device=qkv.device, dtype=qkv.dtype)
+    check(lib().occ_attention(ptr(qkv), ptr(out), dtype_code(qkv), B, T, H, hd, 3 * D, D, float(scale), stream_ptr()), "occ_attention")
+    return out
+
+
+# ---------------------------------------------------------------------------------- RawBoost ---
+def rawboost_fir_bank(x, coef, ntaps, powers):
+    """x f32/f64 [B,L]; coef f64 [B,F,max_taps]; ntaps i32 [B,F] -> y f64 [B,L]."""
+    _dev(x)
+    B, L = x.shape
+    F, max_taps = coef.shape[1], coef.shape[2]
+    y = torch.empty(B, L, device=x.device, dtype=torch.float64)
+    check(lib().occ_rawboost_fir_bank(ptr(x), dtype_code(x), ptr(y), ptr(coef), ptr(ntaps), B, L, F, max_taps, int(powers), stream_ptr()),
+          "occ_rawboost_fir_bank")
+    return y
+
+
+def _partials(B, L, device):
+    return torch.empty(B, (L + 4095) // 4096, 4, device=device, dtype=torch.float64)
+
+
+def rawboost_center_norm(y, subtract_mean, norm_mode):
+    B, L = y.shape
+    check(lib().occ_rawboost_center_norm(ptr(y), B, L, int(subtract_mean), int(norm_mode), ptr(_partials(B, L, y.device)), stream_ptr()),
+          "occ_rawboost_center_norm")
+    return y
+
+
+def rawboost_isd_scatter(y, pos, fr, n, g_sd):
+    B, L = y.shape
+    check(lib().occ_rawboost_isd_scatter(ptr(y), ptr(pos), ptr(fr), ptr(n), B, L, pos.shape[1], float(g_sd), stream_ptr()),
+          "occ_rawboost_isd_scatter")
+    return y
+
+
+def rawboost_ssi_mix(x, noise, snr):
+    B, L = x.shape
+    out = torch.empty_like(x)
+    check(lib().occ_rawboost_ssi_mix(ptr(x), ptr(noise), ptr(snr), ptr(out), B, L, ptr(_partials(B, L, x.device)), stream_ptr()),
+          "occ_rawboost_ssi_mix")
+    return out
+
+
+def add_f64(a, b):
+    out = torch.empty_like(a)
+    check(lib().occ_add_f64(ptr(a), ptr(b), ptr(out), a.numel(), stream_ptr()), "occ_add_f64")
+    return out
+
+
+def cast(src, dtype):
+    dst = torch.empty(src.shape, device=src.device, dtype=dtype)
+    check(lib().occ_cast(ptr(src), dtype_code(src), ptr(dst), dtype_code(dst), src.numel(), stream_ptr()), "occ_cast")
+    return dst
+
+
+def philox_fill(shape, dtype, seed, stream_id, normal, device="cuda"):
+    dst = torch.empty(shape, device=device, dtype=dtype)
+    check(lib().occ_philox_fill(ptr(dst), dtype_code(dst), dst.numel(), int(seed), int(stream_id), int(normal), stream_ptr()), "occ_philox_fill")
+    return dst
+
+
+def notch_coeffs_host(bands, G, fs, max_taps=512):
+    """Host-only: (fc,bw,c) list + gain -> (coef f64[max_taps], ntaps)."""
+    fc = np.ascontiguousarray([b[0] for b in bands], dtype=np.float64)
+    bw = np.ascontiguousarray([b[1] for b in bands], dtype=np.float64)
+    c = np.ascontiguousarray([b[2] for b in bands], dtype=np.int32)
+    out = np.zeros(max_taps, dtype=np.float64)
+    nt = np.zeros(1, dtype=np.int32)
+    check(lib().occ_notch_coeffs_host(ptr(fc), ptr(bw), ptr(c), len(bands), float(G), float(fs), ptr(out), ptr(nt), max_taps),
+          "occ_notch_coeffs_host")
+    return out, int(nt[0])
+
+
+# ------------------------------------------------------------------------------------ losses ---
+def compactness_loss(emb, n_groups=1, group=None, scale=1.0, want_grad=False):
+    _dev(emb)
+    rows, E = emb.shape
+    group = group or rows // n_groups
+    loss = torch.empty(1, device=emb.device, dtype=torch.float32)
+    demb = torch.empty_like(emb) if want_grad else None
+    check(lib().occ_compactness_loss(ptr(emb), ptr(loss), ptr(demb), n_groups, group, E, float(scale), stream_ptr()), "occ_compactness_loss")
+    return loss, demb
+
+
+def ce_loss(logits, labels, scale=1.0, want_grad=False):
+    _dev(logits)
+    B, C = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    dl = torch.empty_like(logits) if want_grad else None
+    check(lib().occ_ce_loss(ptr(logits), ptr(labels), ptr(loss), ptr(dl), B, C, float(scale), stream_ptr()), "occ_ce_loss")
+    return loss, dl
+
+
+def pairwise_dist(ref, emb):
+    _dev(emb)
+    N, E = emb.shape
+    dist = torch.empty(N, device=emb.device, dtype=torch.float32)
+    check(lib().occ_pairwise_dist(ptr(ref), ptr(emb), ptr(dist), N, E, stream_ptr()), "occ_pairwise_dist")
+    return dist
+
+
+class AdamMulti:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) semantics (oc_training.py:324) as one launch."""
+
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        dev = self.params[0].device
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self._p = torch.tensor([p.data_ptr() for p in self.params], dtype=torch.int64, device=dev)
+        self._m = torch.tensor([p.data_ptr() for p in self.exp_avg], dtype=torch.int64, device=dev)
+        self._v = torch.tensor([p.data_ptr() for p in self.exp_avg_sq], dtype=torch.int64, device=dev)
+        self._sizes = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
+        self._max = max(p.numel() for p in self.params)
+        self._g_host = None
+        self._g = None
+
+    def step(self, grads, grad_scale=1.0):
+        """grads: list aligned with params (None = no gradient)."""
+        ptrs = [0 if g is None else g.data_ptr() for g in grads]
+        if self._g_host != ptrs:
+            self._g_host = ptrs
+            self._g = torch.tensor(ptrs, dtype=torch.int64, device=self.params[0].device)
+        self.step_count += 1
+        check(lib().occ_adam_multi(ptr(self._p), ptr(self._g), ptr(self._m), ptr(self._v), ptr(self._sizes), len(self.params), self._max,
+                                   self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, float(grad_scale), stream_ptr()),
+              "occ_adam_multi")

@@ -1,0 +1,120 @@
+"""HIP RawBoost path (through the C ABI) vs the reference's own outputs (tests/golden/rawboost.npz) and
+the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, synth_wave
+
+pytestmark = pytest.mark.gpu
+G = golden("rawboost.npz")
+L = 8000
+
+
+def _args():
+    from oracle.rawboost_np import RawBoostArgs
+    return RawBoostArgs()
+
+
+@pytest.mark.parametrize("algo", list(range(9)))
+@pytest.mark.parametrize("seed", [11, 12])
+def test_process_rawboost_feature_matches_reference(algo, seed):
+    from occm_amd.data_utils_SSL import process_Rawboost_feature
+    x = synth_wave(1000 + seed, L)
+    if algo == 3 and seed == 12:
+        x = x * 12.0
+    np.random.seed(seed)
+    y = process_Rawboost_feature(x, 16000, _args(), algo)
+    ref = G["algo%d_seed%d" % (algo, seed)]
+    assert y.shape == ref.shape and y.dtype == ref.dtype
+    tol = 1e-6 if y.dtype == np.float32 else 1e-9
+    np.testing.assert_allclose(y, ref, rtol=tol, atol=tol * 1e-2)
+
+
+def test_loud_input_peak_normalised():
+    from occm_amd.data_utils_SSL import process_Rawboost_feature
+    x = synth_wave(77, L) * 8.0
+    np.random.seed(5)
+    y = process_Rawboost_feature(x, 16000, _args(), 5)
+    np.testing.assert_allclose(y, G["algo5_loud"], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("nt", [11, 101, 501])
+def test_fir_injected_coefficients(nt):
+    from occm_amd import ops
+    rs = np.random.RandomState(9)
+    b = None
+    for n in (11, 101, 501):
+        bb = rs.randn(n) / n
+        if n == nt:
+            b = bb
+    coef = np.zeros((1, 1, 512)); coef[0, 0, :nt] = b
+    x = synth_wave(90 + nt, L)
+    y = ops.rawboost_fir_bank(torch.from_numpy(x[None]).cuda(), torch.from_numpy(coef).cuda(),
+                              torch.tensor([[nt]], dtype=torch.int32).cuda(), powers=False)
+    np.testing.assert_allclose(y[0].cpu().numpy(), G["fir_%d" % nt], rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("Lx,nts", [(1, (1,)), (5, (3, 1)), (1023, (7, 501)), (1025, (1023,)), (4099, (255, 9, 33))])
+def test_fir_edge_lengths_vs_oracle(Lx, nts):
+    from occm_amd import ops
+    from oracle import rawboost_np as rb
+    rs = np.random.RandomState(Lx)
+    x = (rs.randn(2, Lx) * 0.5).astype(np.float32)
+    F = len(nts)
+    coef = np.zeros((2, F, 1024)); ntaps = np.zeros((2, F), dtype=np.int32)
+    for b in range(2):
+        for f, nt in enumerate(nts):
+            coef[b, f, :nt] = rs.randn(nt) / nt; ntaps[b, f] = nt
+    y = ops.rawboost_fir_bank(torch.from_numpy(x).cuda(), torch.from_numpy(coef).cuda(), torch.from_numpy(ntaps).cuda(), powers=True)
+    y = y.cpu().numpy()
+    for b in range(2):
+        ref = sum(rb.filter_fir(np.power(x[b], f + 1), coef[b, f, :nt]) for f, nt in enumerate(nts))
+        np.testing.assert_allclose(y[b], ref, rtol=1e-9, atol=1e-12)
+
+
+def test_full_size_batch_linearity_and_oracle_spotcheck():
+    """BASELINE size: 64 utterances x 64600 samples.  FIR bank is linear in x (powers off); two rows are
+    also compared with the oracle end to end (LnL incl. mean removal / peak rule)."""
+    from occm_amd import ops
+    from oracle import rawboost_np as rb
+    B, Lf = 64, 64600
+    rs = np.random.RandomState(3)
+    x1 = (rs.randn(B, Lf) * 0.2).astype(np.float32)
+    x2 = (rs.randn(B, Lf) * 0.2).astype(np.float32)
+    coef = np.zeros((B, 5, 512)); ntaps = np.zeros((B, 5), dtype=np.int32)
+    for b in range(B):
+        for f in range(5):
+            nt = int(rs.randint(5, 250)) * 2 + 1
+            coef[b, f, :nt] = rs.randn(nt) / nt; ntaps[b, f] = nt
+    c, n = torch.from_numpy(coef).cuda(), torch.from_numpy(ntaps).cuda()
+    d1, d2 = torch.from_numpy(x1).cuda().double(), torch.from_numpy(x2).cuda().double()
+    y1 = ops.rawboost_fir_bank(d1, c, n, powers=False)
+    y2 = ops.rawboost_fir_bank(d2, c, n, powers=False)
+    y12 = ops.rawboost_fir_bank(2.0 * d1 - 3.0 * d2, c, n, powers=False)
+    torch.testing.assert_close(y12, 2.0 * y1 - 3.0 * y2, rtol=1e-9, atol=1e-10)
+    y = ops.rawboost_center_norm(ops.rawboost_fir_bank(torch.from_numpy(x1).cuda(), c, n, powers=True), True, 1)
+    assert float(y.mean(dim=1).abs().max()) < 1e-12 or float(y.abs().max()) <= 1.0 + 1e-12
+    for b in (0, 63):
+        ref = rb.lnl_convolutive_noise(x1[b], [coef[b, f, :ntaps[b, f]] for f in range(5)])
+        np.testing.assert_allclose(y[b].cpu().numpy(), ref, rtol=1e-9, atol=1e-12)
+
+
+def test_cuda_tensor_in_cuda_tensor_out_and_batch():
+    from occm_amd.data_utils_SSL import process_Rawboost_feature
+    x = np.stack([synth_wave(1011, L), synth_wave(1012, L)])
+    np.random.seed(11)
+    y = process_Rawboost_feature(torch.from_numpy(x).cuda(), 16000, _args(), 1)
+    assert y.is_cuda and y.shape == (2, L) and y.dtype == torch.float64
+    np.testing.assert_allclose(y[0].cpu().numpy(), G["algo1_seed11"], rtol=1e-9, atol=1e-11)
+
+
+def test_philox_fill_statistics_and_determinism():
+    from occm_amd import ops
+    a = ops.philox_fill((1 << 20,), torch.float32, seed=7, stream_id=3, normal=True)
+    b = ops.philox_fill((1 << 20,), torch.float32, seed=7, stream_id=3, normal=True)
+    c = ops.philox_fill((1 << 20,), torch.float32, seed=7, stream_id=4, normal=True)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1.0) < 5e-3
+    u = ops.philox_fill((1 << 20,), torch.float64, seed=1, stream_id=0, normal=False)
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 2e-3
