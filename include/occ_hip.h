@@ -73,20 +73,26 @@ int occ_ce_loss(const float* logits, const int64_t* labels, float* loss, float* 
 int occ_pairwise_dist(const float* ref, const float* emb, float* dist, int64_t N, int64_t E, void* stream);
 
 /* ---------------------------------------------------- optimizer (oc_training.py:324, 385) -- */
-/* torch.optim.Adam step (no weight decay, no amsgrad) over a list of n tensors given as device
- * arrays of pointers/sizes: p -= lr * m_hat / (sqrt(v_hat) + eps).  step >= 1.                    */
+/* torch.optim.Adam step (no weight decay, no amsgrad) over a list of n f32 tensors given as device
+ * arrays of pointers/sizes: p -= lr * m_hat / (sqrt(v_hat) + eps).  A NULL grads[t] skips tensor t
+ * (torch skips parameters whose .grad is None); steps: i32 [n] per-tensor step counters kept on the
+ * device and advanced by this call (torch keeps one step per parameter).  grads are multiplied by
+ * grad_scale first (1/world_size after a summing all-reduce).                                      */
 int occ_adam_multi(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
-                   const int64_t* sizes, int64_t n_tensors, int64_t max_size, float lr, float beta1,
-                   float beta2, float eps, int64_t step, float grad_scale, void* stream);
+                   const int64_t* sizes, int32_t* steps, int64_t n_tensors, int64_t max_size, float lr,
+                   float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------ GEMM family ----------- */
-/* Row addressing shared by A, C and the residual R: row m lives at
- *     base + (m / rows_per_batch) * batch_stride + (m % rows_per_batch) * row_stride     (elements)
+/* Row addressing shared by A, C and the residual R: with r = m % rows_per_batch, row m lives at
+ *     base + (m / rows_per_batch) * batch_stride + r * row_stride                      (elements)
+ * or, when rows_per_line > 0 (2-D images inside padded buffers),
+ *     base + (m / rows_per_batch) * batch_stride + (r / rows_per_line) * line_stride + (r % rows_per_line) * row_stride
  * which expresses plain matrices (rows_per_batch = M), strided-window implicit GEMMs (Conv1d over a
- * channels-last signal: row_stride = stride*C, K = k*C) and writes into zero-padded buffers.
+ * channels-last signal: row_stride = stride*C, K = k*C; Conv2d over channels-last images) and writes
+ * into the interior of zero-padded buffers.
  * A rows may additionally be split into `a_nseg` K-segments of `a_seg_len` contiguous elements that
  * are `a_seg_stride` apart (grouped / 2-D convolutions); a_nseg*a_seg_len == K.                   */
-typedef struct occ_rowmap { int64_t rows_per_batch, batch_stride, row_stride; } occ_rowmap;
+typedef struct occ_rowmap { int64_t rows_per_batch, batch_stride, row_stride, rows_per_line, line_stride; } occ_rowmap;
 typedef struct occ_gemm_desc {
     int64_t M, N, K;
     const void* A; occ_rowmap a_map; int64_t a_nseg, a_seg_len, a_seg_stride;

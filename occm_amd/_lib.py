@@ -17,7 +17,8 @@ class OccError(RuntimeError):
 
 
 class RowMap(ctypes.Structure):
-    _fields_ = [("rows_per_batch", ctypes.c_int64), ("batch_stride", ctypes.c_int64), ("row_stride", ctypes.c_int64)]
+    _fields_ = [("rows_per_batch", ctypes.c_int64), ("batch_stride", ctypes.c_int64), ("row_stride", ctypes.c_int64),
+                ("rows_per_line", ctypes.c_int64), ("line_stride", ctypes.c_int64)]
 
 
 class GemmDesc(ctypes.Structure):

@@ -23,7 +23,7 @@ constexpr int TM = 128, TN = 128, THREADS = 256;
 constexpr int SLAB_BYTES = 128;                 // K bytes per row per slab
 constexpr int CHUNKS = SLAB_BYTES / 16;         // 8 chunks of 16 B per row
 
-struct RowMapI { long long rpb, bstride, rstride; };
+struct RowMapI { long long rpb, bstride, rstride, rpl, lstride; };
 
 struct GemmArgs {
     long long M, N, K;
@@ -39,7 +39,9 @@ struct GemmArgs {
 
 __device__ __forceinline__ long long row_off(const RowMapI& m, long long row) {
     const long long b = row / m.rpb;
-    return b * m.bstride + (row - b * m.rpb) * m.rstride;
+    const long long r = row - b * m.rpb;
+    if (m.rpl > 0) { const long long l = r / m.rpl; return b * m.bstride + l * m.lstride + (r - l * m.rpl) * m.rstride; }
+    return b * m.bstride + r * m.rstride;
 }
 
 __device__ __forceinline__ float act_rt(int act, float v) {
@@ -220,6 +222,8 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     OCC_CHECK_ARG(nseg * seg_len == d->K, "occ_gemm: a_nseg*a_seg_len != K");
     OCC_CHECK_ARG(seg_len % ce == 0 && (nseg == 1 || d->a_seg_stride % ce == 0), "occ_gemm: K segments must be 16-byte granular");
     OCC_CHECK_ARG(d->a_map.rows_per_batch >= 1 && d->c_map.rows_per_batch >= 1, "occ_gemm: rows_per_batch must be >= 1");
+    OCC_CHECK_ARG(d->a_map.line_stride % ce == 0 && d->c_map.line_stride % 4 == 0 && (!d->R || d->r_map.line_stride % 4 == 0),
+                  "occ_gemm: line strides must keep rows 16-byte aligned");
     OCC_CHECK_ARG(d->a_map.row_stride % ce == 0 && d->a_map.batch_stride % ce == 0 && d->ldw % ce == 0 && d->ldw >= d->K,
                   "occ_gemm: A/W strides must keep rows 16-byte aligned");
     OCC_CHECK_ARG(d->c_map.row_stride % 4 == 0 && d->c_map.batch_stride % 4 == 0, "occ_gemm: C strides must be multiples of 4 elements");
@@ -228,12 +232,12 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     if (d->R) OCC_CHECK_ARG(d->r_map.rows_per_batch >= 1 && d->r_map.row_stride % 4 == 0 && d->r_map.batch_stride % 4 == 0, "occ_gemm: bad residual map");
     GemmArgs a;
     a.M = d->M; a.N = d->N; a.K = d->K;
-    a.X = (const char*)d->A; a.xmap = {d->a_map.rows_per_batch, d->a_map.batch_stride, d->a_map.row_stride};
+    a.X = (const char*)d->A; a.xmap = {d->a_map.rows_per_batch, d->a_map.batch_stride, d->a_map.row_stride, d->a_map.rows_per_line, d->a_map.line_stride};
     a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->a_seg_stride;
     a.W = (const char*)d->W; a.ldw = d->ldw;
     a.bias = (const float*)d->bias;
-    a.R = (const char*)d->R; a.rmap = {d->r_map.rows_per_batch, d->r_map.batch_stride, d->r_map.row_stride}; a.r_dtype = d->r_dtype;
-    a.C = (char*)d->C; a.cmap = {d->c_map.rows_per_batch, d->c_map.batch_stride, d->c_map.row_stride}; a.c_dtype = d->c_dtype;
+    a.R = (const char*)d->R; a.rmap = {d->r_map.rows_per_batch, d->r_map.batch_stride, d->r_map.row_stride, d->r_map.rows_per_line, d->r_map.line_stride}; a.r_dtype = d->r_dtype;
+    a.C = (char*)d->C; a.cmap = {d->c_map.rows_per_batch, d->c_map.batch_stride, d->c_map.row_stride, d->c_map.rows_per_line, d->c_map.line_stride}; a.c_dtype = d->c_dtype;
     a.act = d->act; a.alpha = d->alpha;
     a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
     const long long ng = d->n_groups > 1 ? d->n_groups : 1;

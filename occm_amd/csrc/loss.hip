@@ -102,11 +102,20 @@ __global__ void pairwise_dist_kernel(const float* __restrict__ ref, const float*
     if (lane == 0) dist[row] = sqrtf(s);
 }
 
+// torch.optim.Adam keeps one step counter per parameter and skips parameters whose grad is None.
+__global__ void adam_bump_steps_kernel(void* const* __restrict__ grads, int32_t* __restrict__ steps, int n) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && grads[t] != nullptr) steps[t] += 1;
+}
+
 __global__ __launch_bounds__(256) void adam_multi_kernel(void* const* __restrict__ params, void* const* __restrict__ grads,
                                                          void* const* __restrict__ m1, void* const* __restrict__ m2,
-                                                         const int64_t* __restrict__ sizes, float lr, float b1, float b2, float eps,
-                                                         float bc1, float bc2_sqrt, float gscale) {
+                                                         const int64_t* __restrict__ sizes, const int32_t* __restrict__ steps,
+                                                         float lr, float b1, float b2, float eps, float gscale) {
     const int t = blockIdx.y;
+    const float stepf = (float)steps[t];
+    const float bc1 = 1.f - powf(b1, stepf);
+    const float bc2_sqrt = sqrtf(1.f - powf(b2, stepf));
     const int64_t n = sizes[t];
     float* p = (float*)params[t];
     const float* g = (const float*)grads[t];
@@ -152,15 +161,16 @@ int occ_pairwise_dist(const float* ref, const float* emb, float* dist, int64_t N
 }
 
 int occ_adam_multi(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq, const int64_t* sizes,
-                   int64_t n_tensors, int64_t max_size, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale, void* stream) {
-    OCC_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && sizes, "occ_adam_multi: null pointer");
-    OCC_CHECK_ARG(n_tensors >= 1 && n_tensors < 65536 && step >= 1 && max_size >= 1, "occ_adam_multi: bad argument");
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2 = 1.f - powf(beta2, (float)step);
+                   int32_t* steps, int64_t n_tensors, int64_t max_size, float lr, float beta1, float beta2, float eps, float grad_scale,
+                   void* stream) {
+    OCC_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && sizes && steps, "occ_adam_multi: null pointer");
+    OCC_CHECK_ARG(n_tensors >= 1 && n_tensors < 65536 && max_size >= 1, "occ_adam_multi: bad argument");
     int64_t bx = occ_cdiv(max_size, 256 * 4);
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, sizes, lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_bump_steps_kernel, dim3((unsigned)occ_cdiv(n_tensors, 256)), dim3(256), 0, s, grads, steps, (int)n_tensors);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, s, params, grads, exp_avg,
+                       exp_avg_sq, sizes, (const int32_t*)steps, lr, beta1, beta2, eps, grad_scale);
     OCC_LAUNCH_CHECK("occ_adam_multi");
     return OCC_OK;
 }

@@ -19,8 +19,8 @@ def _dev(t):
     return t
 
 
-def rowmap(rows_per_batch, batch_stride, row_stride):
-    return RowMap(int(rows_per_batch), int(batch_stride), int(row_stride))
+def rowmap(rows_per_batch, batch_stride, row_stride, rows_per_line=0, line_stride=0):
+    return RowMap(int(rows_per_batch), int(batch_stride), int(row_stride), int(rows_per_line), int(line_stride))
 
 
 def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, act=ACT_NONE, alpha=1.0,
@@ -210,6 +210,7 @@ class AdamMulti:
         self._m = torch.tensor([p.data_ptr() for p in self.exp_avg], dtype=torch.int64, device=dev)
         self._v = torch.tensor([p.data_ptr() for p in self.exp_avg_sq], dtype=torch.int64, device=dev)
         self._sizes = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
+        self._steps = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
         self._max = max(p.numel() for p in self.params)
         self._g_host = None
         self._g = None
@@ -221,6 +222,6 @@ class AdamMulti:
             self._g_host = ptrs
             self._g = torch.tensor(ptrs, dtype=torch.int64, device=self.params[0].device)
         self.step_count += 1
-        check(lib().occ_adam_multi(ptr(self._p), ptr(self._g), ptr(self._m), ptr(self._v), ptr(self._sizes), len(self.params), self._max,
-                                   self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, float(grad_scale), stream_ptr()),
-              "occ_adam_multi")
+        check(lib().occ_adam_multi(ptr(self._p), ptr(self._g), ptr(self._m), ptr(self._v), ptr(self._sizes), ptr(self._steps),
+                                   len(self.params), self._max, self.lr, self.betas[0], self.betas[1], self.eps, float(grad_scale),
+                                   stream_ptr()), "occ_adam_multi")

@@ -158,7 +158,7 @@ def test_xlsr_frontend_f32_matches_oracle(L):
 
 
 def test_xlsr_frontend_bf16_close_to_oracle():
-    """bf16 operands / f32 accumulate: stated bound 6e-2 absolute on unit-variance (LayerNormed) outputs."""
+    """bf16 operands / f32 accumulate: stated bound 6e-2 max, 1e-2 mean absolute on unit-variance (LayerNormed) outputs."""
     from oracle import xlsr_ref
     from oracle.fill import fill_like
     from occm_amd.models import xlsr
@@ -169,7 +169,7 @@ def test_xlsr_frontend_bf16_close_to_oracle():
         ref = xlsr_ref.extract_feat(wav, p, rcfg)
     out = xlsr.XlsrFrontend(p, cfg, dtype=torch.bfloat16).forward(wav.cuda(), out_dtype=torch.float32).cpu()
     err = (out - ref).abs()
-    assert float(err.max()) < 6e-2 and float(err.mean()) < 6e-3, (float(err.max()), float(err.mean()))
+    assert float(err.max()) < 6e-2 and float(err.mean()) < 1e-2, (float(err.max()), float(err.mean()))
 
 
 def test_sslmodel_dropin_surface():
