@@ -111,6 +111,117 @@ typedef struct occ_gemm_desc {
  * (fairseq wav2vec2 layers reached from sslassist.py:48; AModel.LL sslassist.py:509).             */
 int occ_gemm(const occ_gemm_desc* d, void* stream);
 
+
+/* Weight-gradient GEMM (f32): C[n1,n2] += alpha * sum_m A[m,n1] * B[m,n2]; A rows [N1] and B rows [N2] go through
+ * row maps, B rows may be K-segmented conv windows; C f32 [N1, ldc] is accumulated with atomics.  Backward of
+ * the Linear / Conv2d weights of the AASIST back-end.                                               */
+typedef struct occ_gemm_tn_desc {
+    int64_t M, N1, N2;
+    const void* A; occ_rowmap a_map;
+    const void* B; occ_rowmap b_map; int64_t b_nseg, b_seg_len, b_seg_stride;
+    void* C; int64_t ldc;
+    float alpha;
+} occ_gemm_tn_desc;
+int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream);
+/* out[n] += alpha * sum_m A[m,n] (bias gradients).                                                   */
+int occ_colsum(const float* A, const occ_rowmap* a_map, int64_t M, int64_t N, float* out, float alpha, void* stream);
+
+/* --------------------------------------------- AASIST back-end (models/sslassist.py:58-597), f32 ---- */
+int occ_fill_f32(float* p, float v, int64_t n, void* stream);
+int occ_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream);   /* b may be NULL */
+/* out[i0,i1,i2,i3] (contiguous) (+)= in[offset + sum i_k*stride_k]; shape/strides are HOST arrays of 4.  Used to
+ * repack weights (flip / transpose) between the checkpoint layout and the GEMM layouts.              */
+int occ_copy_strided(const float* in, float* out, int64_t offset, const int64_t* shape4_host, const int64_t* strides4_host,
+                     int accumulate, void* stream);
+/* y[y_map(r), :C] (+)= x[x_map(r), :C]: split / concatenate node sets, move rows in and out of padded buffers. */
+int occ_copy_rows(const float* x, const occ_rowmap* x_map, float* y, const occ_rowmap* y_map, int64_t rows, int64_t C,
+                  int accumulate, void* stream);
+/* dx = dy * act'(.) with the derivative expressed through the activation OUTPUT y (GEMM-fused SELU / tanh / relu). */
+int occ_act_bwd(const float* dy, const float* y, float* dx, int act, int64_t n, void* stream);
+/* nn.Dropout: y = x*mask/(1-p); generate != 0 draws the keep-mask (Philox) and stores it, else uses the given mask. */
+int occ_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t stream_id,
+                int generate, void* stream);
+/* F.max_pool2d(LL(x).transpose(1,2).unsqueeze(1), (3,3)) (sslassist.py:512-514): y [B,T,F] -> out [B,F/3,T/3] written
+ * with element stride out_c, idx = window argmax; bwd scatters dout back into dy [B,T,F] (pre-zeroed).   */
+int occ_stem_pool_fwd(const float* y, float* out, uint8_t* idx, int64_t B, int64_t T, int64_t F, int64_t out_c, void* stream);
+int occ_stem_pool_bwd(const float* dout, const uint8_t* idx, float* dy, int64_t B, int64_t T, int64_t F, int64_t dout_c, void* stream);
+/* BatchNorm (nn.BatchNorm1d/2d on channels-last rows) split as statistics + fused normalise/activation.
+ * train: batch mean / biased variance -> mean,rstd (may be NULL to only move the running stats), running stats
+ * updated with momentum (unbiased variance) like torch; eval: mean,rstd from the running stats.
+ * ws: f64 scratch [512*C*2]; 256 % C == 0.                                                            */
+int occ_bn_stats(const float* x, const occ_rowmap* x_map, int64_t rows, int64_t C, double* ws, float* mean, float* rstd,
+                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int train,
+                 void* stream);
+int occ_bn_act_fwd(const float* x, const occ_rowmap* x_map, const float* mean, const float* rstd, const float* gamma,
+                   const float* beta, int act, float* y, const occ_rowmap* y_map, int64_t rows, int64_t C, void* stream);
+/* dx = d/dx of act(BN(x)) given dy (train-mode statistics); dgamma/dbeta (may be NULL) are accumulated; sums: f32 [2C] scratch. */
+int occ_bn_act_bwd(const float* dy, const occ_rowmap* dy_map, const float* x, const occ_rowmap* x_map, const float* mean,
+                   const float* rstd, const float* gamma, const float* beta, int act, float* dx, const occ_rowmap* dx_map,
+                   float* dgamma, float* dbeta, double* ws, float* sums, int64_t rows, int64_t C, void* stream);
+/* out[o,c] = sum_r x*softmax_r(w) (+pos[o % pos_period, c]) with element (o,r,c) at
+ * (o/inner_n)*outer_stride + (o%inner_n)*inner_stride + r*r_stride + c  (sslassist.py:526-538).          */
+int occ_softmax_wsum_fwd(const float* x, const float* w, int64_t n_outer, int64_t inner_n, int64_t outer_stride,
+                         int64_t inner_stride, int64_t R, int64_t r_stride, int64_t C, const float* pos, int64_t pos_period,
+                         float* out, void* stream);
+int occ_softmax_wsum_bwd(const float* x, const float* w, int64_t n_outer, int64_t inner_n, int64_t outer_stride,
+                         int64_t inner_stride, int64_t R, int64_t r_stride, int64_t C, const float* dm, float* dx, float* dw,
+                         int accumulate, void* stream);
+/* GraphAttentionLayer / HtrgGraphAttentionLayer pieces (sslassist.py:58-151, 154-329); x [B,N,D], P/A [B,N,N,D], alpha [B,N,N]. */
+int occ_pair_mul(const float* x, float* P, int64_t B, int64_t N, int64_t D, void* stream);
+int occ_pair_mul_bwd(const float* dP, const float* x, float* dx, int64_t B, int64_t N, int64_t D, int accumulate, void* stream);
+/* alpha = softmax_j(A . aw_type(i,j) * inv_temp); aw f32 [3][Do] = (att_weight11, att_weight22, att_weight12), n1 = #type-1 nodes
+ * (homogeneous layers: n1 = N, only the first vector is used).                                           */
+int occ_gat_softmax(const float* A, const float* aw, int64_t B, int64_t N, int64_t Do, int64_t n1, float inv_temp, float* alpha,
+                    void* stream);
+/* trans=0: out[b,i,:] (+)= sum_j alpha[b,i,j] x[b,j,:];  trans=1: out[b,j,:] (+)= sum_i alpha[b,i,j] x[b,i,:].   */
+int occ_bmm_alpha(const float* alpha, const float* x, float* out, int64_t B, int64_t N, int64_t D, int trans, int accumulate,
+                  void* stream);
+int occ_gat_dscore(const float* alpha, const float* dh, const float* x, float* ds, int64_t B, int64_t N, int64_t D, float inv_temp,
+                   void* stream);
+/* in place A <- dZ = ds*aw_type*(1-A^2); daw [3][Do] += sum ds*A.                                          */
+int occ_gat_dz(float* A, const float* ds, const float* aw, int64_t B, int64_t N, int64_t Do, int64_t n1, float* daw, void* stream);
+/* master-node update of HtrgGraphAttentionLayer (sslassist.py:234-239, 255-270, 310-316).                */
+typedef struct occ_master_desc {
+    int64_t B, N, D, Do;
+    const float* x;                    /* [B,N,D] concatenated, dropped-out node features */
+    const float* master; int64_t master_bstride;   /* [B,D] (stride D) or the shared parameter [1,D] (stride 0) */
+    const float *att_projM_w, *att_projM_b, *att_weightM, *proj_with_attM_w, *proj_with_attM_b, *proj_without_attM_w,
+        *proj_without_attM_b;
+    float inv_temp;
+    float* out;                        /* [B,Do] new master */
+    float *am, *agg;                   /* saved for backward: [B,N], [B,D] */
+} occ_master_desc;
+typedef struct occ_master_grads {
+    const float* dout;                 /* [B,Do] */
+    float* dx; int dx_accumulate;      /* [B,N,D] */
+    float* dmaster; int64_t dmaster_bstride;       /* accumulated atomically */
+    float *d_att_projM_w, *d_att_projM_b, *d_att_weightM, *d_proj_with_attM_w, *d_proj_with_attM_b, *d_proj_without_attM_w,
+        *d_proj_without_attM_b;        /* accumulated atomically */
+} occ_master_grads;
+int occ_master_fwd(const occ_master_desc* d, void* stream);
+int occ_master_bwd(const occ_master_desc* d, const occ_master_grads* g, void* stream);
+/* GraphPool (sslassist.py:332-368): scores = sigmoid(proj(drop(h))), keep the k best nodes, out = h*score in rank order. */
+int occ_graph_pool_fwd(const float* h, const uint8_t* mask, float drop_p, const float* w, const float* bias, int64_t B, int64_t N,
+                       int64_t D, int64_t k, float* out, int32_t* idx, float* scores, void* stream);
+int occ_graph_pool_bwd(const float* h, const uint8_t* mask, float drop_p, const float* w, const float* scores, const int32_t* idx,
+                       const float* dout, int64_t B, int64_t N, int64_t D, int64_t k, float* dh, float* dw, float* dbias, void* stream);
+/* read-out + classifier (sslassist.py:573-597); masks are keep-masks (NULL = no dropout).                 */
+typedef struct occ_readout_desc {
+    int64_t B, Nt, Ns, Dg, n_classes;
+    const float *T1, *T2, *S1, *S2, *M1, *M2;
+    const uint8_t *mask_T1, *mask_T2, *mask_S1, *mask_S2, *mask_M1, *mask_M2, *mask_last;
+    float p_way, p_last;
+    const float *out_w, *out_b;
+    float *emb, *logits;
+} occ_readout_desc;
+typedef struct occ_readout_grads {
+    const float *demb, *dlogits;
+    float *dT1, *dT2, *dS1, *dS2, *dM1, *dM2;
+    float *d_out_w, *d_out_b;
+} occ_readout_grads;
+int occ_readout_fwd(const occ_readout_desc* d, void* stream);
+int occ_readout_bwd(const occ_readout_desc* d, const occ_readout_grads* g, void* stream);
+
 /* ------------------------------------------------------------- front-end row kernels ------- */
 /* y = LayerNorm(x) * gamma + beta, optional GELU, over rows of width C (C % 64 == 0, C <= 8192).
  * fairseq LayerNorm / Fp32LayerNorm + GELU of the conv blocks and transformer layers.            */

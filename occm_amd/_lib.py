@@ -34,6 +34,44 @@ class GemmDesc(ctypes.Structure):
                 ("w_group_stride", ctypes.c_int64), ("c_group_stride", ctypes.c_int64)]
 
 
+class GemmTnDesc(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int64), ("N1", ctypes.c_int64), ("N2", ctypes.c_int64),
+                ("A", ctypes.c_void_p), ("a_map", RowMap),
+                ("B", ctypes.c_void_p), ("b_map", RowMap), ("b_nseg", ctypes.c_int64), ("b_seg_len", ctypes.c_int64),
+                ("b_seg_stride", ctypes.c_int64),
+                ("C", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("alpha", ctypes.c_float)]
+
+
+_P = ctypes.c_void_p
+
+
+class MasterDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int64), ("N", ctypes.c_int64), ("D", ctypes.c_int64), ("Do", ctypes.c_int64),
+                ("x", _P), ("master", _P), ("master_bstride", ctypes.c_int64),
+                ("att_projM_w", _P), ("att_projM_b", _P), ("att_weightM", _P), ("proj_with_attM_w", _P), ("proj_with_attM_b", _P),
+                ("proj_without_attM_w", _P), ("proj_without_attM_b", _P),
+                ("inv_temp", ctypes.c_float), ("out", _P), ("am", _P), ("agg", _P)]
+
+
+class MasterGrads(ctypes.Structure):
+    _fields_ = [("dout", _P), ("dx", _P), ("dx_accumulate", ctypes.c_int), ("dmaster", _P), ("dmaster_bstride", ctypes.c_int64),
+                ("d_att_projM_w", _P), ("d_att_projM_b", _P), ("d_att_weightM", _P), ("d_proj_with_attM_w", _P),
+                ("d_proj_with_attM_b", _P), ("d_proj_without_attM_w", _P), ("d_proj_without_attM_b", _P)]
+
+
+class ReadoutDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int64), ("Nt", ctypes.c_int64), ("Ns", ctypes.c_int64), ("Dg", ctypes.c_int64), ("n_classes", ctypes.c_int64),
+                ("T1", _P), ("T2", _P), ("S1", _P), ("S2", _P), ("M1", _P), ("M2", _P),
+                ("mask_T1", _P), ("mask_T2", _P), ("mask_S1", _P), ("mask_S2", _P), ("mask_M1", _P), ("mask_M2", _P), ("mask_last", _P),
+                ("p_way", ctypes.c_float), ("p_last", ctypes.c_float),
+                ("out_w", _P), ("out_b", _P), ("emb", _P), ("logits", _P)]
+
+
+class ReadoutGrads(ctypes.Structure):
+    _fields_ = [("demb", _P), ("dlogits", _P), ("dT1", _P), ("dT2", _P), ("dS1", _P), ("dS2", _P), ("dM1", _P), ("dM2", _P),
+                ("d_out_w", _P), ("d_out_b", _P)]
+
+
 _SCALARS = [("uint64_t", ctypes.c_uint64), ("int64_t", ctypes.c_int64), ("int32_t", ctypes.c_int32),
             ("double", ctypes.c_double), ("float", ctypes.c_float), ("int", ctypes.c_int)]
 

@@ -220,6 +220,130 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA attention for short sequences (T <= 32*NP <= 256, head_dim 64): one workgroup per
+// (batch, head, 64-query block), one wave per 16 queries.  K of the head sits in LDS as swizzled
+// 128-byte rows, V transposed ([d][key]) so both MFMA operands are 8/16-byte LDS reads.
+//   S^T = K.Q^T  (v_mfma_f32_16x16x32_bf16, A = K rows, B = Q): a lane holds 4 consecutive keys of ONE
+//   query, so the softmax row reduction is registers + two xor-shuffles, and the packed probabilities
+//   are already the A operand of O = P.V with the key slots permuted identically on the V^T operand.
+typedef __attribute__((ext_vector_type(4))) float af32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
+
+template <int NP>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
+                                                            int Tn, int H, long long ld_qkv, long long ld_out, float scale) {
+    constexpr int NK = NP * 32;            // padded key count
+    constexpr int VS = NK + 4;             // V^T row stride (elements): 8-byte aligned, bank-spreading
+    __shared__ uint4 Ks[NK * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[64 * VS];
+    const int D = H * 64;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int q0 = blockIdx.y * 64;
+    const unsigned short* base = qkv + (size_t)b * Tn * ld_qkv + (size_t)h * 64;
+    for (int idx = threadIdx.x; idx < NK * 8; idx += 256) {
+        const int key = idx >> 3, ch = idx & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < Tn) {
+            kv = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + D + ch * 8);
+            vv = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + 2 * D + ch * 8);
+        }
+        Ks[key * 8 + (ch ^ (key & 7))] = kv;
+        const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Vt[(ch * 8 + 2 * e) * VS + key] = (unsigned short)(w[e] & 0xffff);
+            Vt[(ch * 8 + 2 * e + 1) * VS + key] = (unsigned short)(w[e] >> 16);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int qrow = q0 + wave * 16 + fr;
+    if (q0 + wave * 16 >= Tn) return;                       // whole wave out of range (wave-uniform)
+    const int qld = qrow < Tn ? qrow : Tn - 1;
+    uint4 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = *reinterpret_cast<const uint4*>(base + (size_t)qld * ld_qkv + s * 32 + g * 8);
+
+    af32x4 sc[2 * NP];
+#pragma unroll
+    for (int t = 0; t < 2 * NP; ++t) {
+        sc[t] = (af32x4){0.f, 0.f, 0.f, 0.f};
+        const int kr = t * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 kf = Ks[kr * 8 + ((s * 4 + g) ^ (kr & 7))];
+            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<abf16x8*>(&kf), *reinterpret_cast<abf16x8*>(&qf[s]), sc[t], 0, 0, 0);
+        }
+    }
+    const float c = scale * 1.44269504088896340736f;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < 2 * NP; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = t * 16 + g * 4 + r;
+            const float v = key < Tn ? sc[t][r] * c : -3.0e38f;
+            sc[t][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2 * NP; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(sc[t][r] - mx);
+            sc[t][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    af32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (af32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        unsigned pw[4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            pw[e] = (unsigned)f32_to_bf16_bits(sc[2 * u][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u][2 * e + 1]) << 16);
+            pw[2 + e] = (unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e + 1]) << 16);
+        }
+        uint4 pf = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const unsigned short* vr = Vt + (dt * 16 + fr) * VS + u * 32 + g * 4;
+            const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+            const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+            uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<abf16x8*>(&pf), *reinterpret_cast<abf16x8*>(&vf), oacc[dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ql = g * 4 + r;
+        const float iv = __shfl(inv, ql, 64);
+        const int q = q0 + wave * 16 + ql;
+        if (q < Tn) {
+            unsigned short* orow = out + ((size_t)b * Tn + q) * ld_out + (size_t)h * 64 + fr;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) orow[dt * 16] = f32_to_bf16_bits(oacc[dt][r] * iv);
+        }
+    }
+}
+
+template <int NP>
+void launch_attention_mfma(const void* qkv, void* out, int B, int T, int H, long long ld_qkv, long long ld_out, float scale, hipStream_t s) {
+    const dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64)), block(256);
+    hipLaunchKernelGGL(attention_mfma_kernel<NP>, grid, block, 0, s, (const unsigned short*)qkv, (unsigned short*)out, T, H, ld_qkv, ld_out, scale);
+}
+
 }  // namespace
 
 extern "C" {
@@ -263,11 +387,21 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
     OCC_CHECK_ARG(B >= 1 && T >= 1 && H >= 1 && hd >= 8 && hd <= 128, "occ_attention: bad shape");
     OCC_CHECK_ARG(T <= 1024, "occ_attention: T=%ld exceeds the short-sequence limit 1024", (long)T);
     OCC_CHECK_ARG(ld_qkv >= 3 * H * hd && ld_out >= H * hd, "occ_attention: leading dimensions too small");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == OCC_BF16 && hd == 64 && T <= 256 && ld_qkv % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) {
+        const int np = (int)((T + 31) / 32);
+        if (np <= 1) launch_attention_mfma<1>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, s);
+        else if (np <= 2) launch_attention_mfma<2>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, s);
+        else if (np <= 4) launch_attention_mfma<4>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, s);
+        else if (np <= 7) launch_attention_mfma<7>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, s);
+        else launch_attention_mfma<8>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, s);
+        OCC_LAUNCH_CHECK("occ_attention(mfma)");
+        return OCC_OK;
+    }
     const size_t shm = ((size_t)2 * T * (hd + 1) + 4 * T + 4 * hd) * sizeof(float);
     OCC_CHECK_ARG(shm <= 160 * 1024, "occ_attention: T=%ld hd=%ld needs %zu B of LDS (> 160 KiB)", (long)T, (long)hd, shm);
     const int qsplit = 4;
     const dim3 grid((unsigned)(B * H), qsplit), block(256);
-    hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (dtype == OCC_F32) {
         e = hipFuncSetAttribute((const void*)attention_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

@@ -23,8 +23,6 @@ constexpr int TM = 128, TN = 128, THREADS = 256;
 constexpr int SLAB_BYTES = 128;                 // K bytes per row per slab
 constexpr int CHUNKS = SLAB_BYTES / 16;         // 8 chunks of 16 B per row
 
-struct RowMapI { long long rpb, bstride, rstride, rpl, lstride; };
-
 struct GemmArgs {
     long long M, N, K;
     const char* X; RowMapI xmap; long long nseg, seg_len, seg_stride;
@@ -36,13 +34,6 @@ struct GemmArgs {
     int nbm, nbn;
     long long a_gstride, w_gstride, c_gstride;
 };
-
-__device__ __forceinline__ long long row_off(const RowMapI& m, long long row) {
-    const long long b = row / m.rpb;
-    const long long r = row - b * m.rpb;
-    if (m.rpl > 0) { const long long l = r / m.rpl; return b * m.bstride + l * m.lstride + (r - l * m.rpl) * m.rstride; }
-    return b * m.bstride + r * m.rstride;
-}
 
 __device__ __forceinline__ float act_rt(int act, float v) {
     switch (act) {
@@ -232,12 +223,12 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     if (d->R) OCC_CHECK_ARG(d->r_map.rows_per_batch >= 1 && d->r_map.row_stride % 4 == 0 && d->r_map.batch_stride % 4 == 0, "occ_gemm: bad residual map");
     GemmArgs a;
     a.M = d->M; a.N = d->N; a.K = d->K;
-    a.X = (const char*)d->A; a.xmap = {d->a_map.rows_per_batch, d->a_map.batch_stride, d->a_map.row_stride, d->a_map.rows_per_line, d->a_map.line_stride};
+    a.X = (const char*)d->A; a.xmap = to_rowmap(d->a_map);
     a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->a_seg_stride;
     a.W = (const char*)d->W; a.ldw = d->ldw;
     a.bias = (const float*)d->bias;
-    a.R = (const char*)d->R; a.rmap = {d->r_map.rows_per_batch, d->r_map.batch_stride, d->r_map.row_stride, d->r_map.rows_per_line, d->r_map.line_stride}; a.r_dtype = d->r_dtype;
-    a.C = (char*)d->C; a.cmap = {d->c_map.rows_per_batch, d->c_map.batch_stride, d->c_map.row_stride, d->c_map.rows_per_line, d->c_map.line_stride}; a.c_dtype = d->c_dtype;
+    a.R = (const char*)d->R; a.rmap = to_rowmap(d->r_map); a.r_dtype = d->r_dtype;
+    a.C = (char*)d->C; a.cmap = to_rowmap(d->c_map); a.c_dtype = d->c_dtype;
     a.act = d->act; a.alpha = d->alpha;
     a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
     const long long ng = d->n_groups > 1 ? d->n_groups : 1;

@@ -1,0 +1,160 @@
+// Weight-gradient GEMM for gfx950 (f32, exact-f32 MFMA):   C[n1, n2] += sum_m A[m, n1] * B[m, n2]
+//   A: [M, N1] rows through an occ_rowmap (dY of a Linear / conv layer, N1 contiguous)
+//   B: [M, N2] rows through an occ_rowmap + K-segments (the layer input, or its conv windows)
+//   C: f32 [N1, ldc], accumulated with float atomics (the M range is split over workgroups)
+// and the matching bias gradient  out[n] += sum_m A[m, n].
+// Backward of every nn.Linear / Conv2d weight of the AASIST back-end (sslassist.py:58-504).
+//
+// Workgroup = 4 waves, output tile 64(n1) x 64(n2); 32-row slabs of A and B are staged in LDS
+// (row stride 80 floats: the 4 k-groups of a 16x16x4 MFMA land on disjoint bank sets) and every wave
+// owns a 32x32 quadrant = 2x2 MFMA tiles.  v_mfma_f32_16x16x4_f32 takes ONE f32 per lane for each
+// operand, so no transposed copy of either operand is ever materialised.
+#include "occ_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr int TT = 64, SLAB = 32, LDS_STRIDE = 80, THREADS = 256;
+
+struct TnArgs {
+    long long M, N1, N2;
+    const float* A; RowMapI amap;
+    const float* B; RowMapI bmap; long long nseg, seg_len, seg_stride;
+    float* C; long long ldc;
+    long long rows_per_split;
+    float alpha;
+};
+
+__global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[SLAB * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Bs[SLAB * LDS_STRIDE];
+    const long long n1_0 = (long long)blockIdx.x * TT, n2_0 = (long long)blockIdx.y * TT;
+    const long long m_begin = (long long)blockIdx.z * a.rows_per_split;
+    const long long m_end = m_begin + a.rows_per_split < a.M ? m_begin + a.rows_per_split : a.M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1, fr = lane & 15, g = lane >> 4;
+
+    // staging: thread copies float4 #c4 of rows srow, srow+16
+    const int c4 = tid & 15, srow = tid >> 4;
+    const long long n1c = n1_0 + c4 * 4, n2c = n2_0 + c4 * 4;
+    const bool a_ok = n1c < a.N1, b_ok = n2c < a.N2;      // N1, N2 are multiples of 4
+    long long bseg_off = 0;
+    if (b_ok) {
+        if (a.nseg > 1) { const long long sg = n2c / a.seg_len; bseg_off = sg * a.seg_stride + (n2c - sg * a.seg_len); }
+        else bseg_off = n2c;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (long long m0 = m_begin; m0 < m_end; m0 += SLAB) {
+        float4 va[2], vb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long m = m0 + srow + 16 * i;
+            va[i] = make_float4(0.f, 0.f, 0.f, 0.f); vb[i] = va[i];
+            if (m < m_end) {
+                if (a_ok) va[i] = *reinterpret_cast<const float4*>(a.A + row_off(a.amap, m) + n1c);
+                if (b_ok) vb[i] = *reinterpret_cast<const float4*>(a.B + row_off(a.bmap, m) + bseg_off);
+            }
+        }
+        __syncthreads();                                   // previous slab fully consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4*>(&As[(srow + 16 * i) * LDS_STRIDE + c4 * 4]) = va[i];
+            *reinterpret_cast<float4*>(&Bs[(srow + 16 * i) * LDS_STRIDE + c4 * 4]) = vb[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < SLAB / 4; ++ks) {
+            const int kr = (ks * 4 + g) * LDS_STRIDE;
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { af[i] = As[kr + wi * 32 + i * 16 + fr]; bf[i] = Bs[kr + wj * 32 + i * 16 + fr]; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[row = n1 (A index)][col = n2]: lane holds col fr, rows 4g + r
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n2 = n2_0 + wj * 32 + j * 16 + fr;
+            if (n2 >= a.N2) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long n1 = n1_0 + wi * 32 + i * 16 + g * 4 + r;
+                if (n1 < a.N1) atomicAdd(a.C + n1 * a.ldc + n2, acc[i][j][r] * a.alpha);
+            }
+        }
+}
+
+// out[n] += alpha * sum_m A[m, n]
+__global__ __launch_bounds__(THREADS) void colsum_kernel(const float* __restrict__ A, RowMapI amap, long long M, long long N,
+                                                         long long rows_per_split, float* __restrict__ out, float alpha) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n = (long long)blockIdx.x * 64 + lane;
+    const long long m_begin = (long long)blockIdx.y * rows_per_split;
+    const long long m_end = m_begin + rows_per_split < M ? m_begin + rows_per_split : M;
+    float s = 0.f;
+    if (n < N)
+        for (long long m = m_begin + wave; m < m_end; m += 4) s += A[row_off(amap, m) + n];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) atomicAdd(out + n, (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * alpha);
+}
+
+}  // namespace
+
+extern "C" {
+
+int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
+    OCC_CHECK_ARG(d && d->A && d->B && d->C, "occ_gemm_tn: null operand");
+    OCC_CHECK_ARG(d->M >= 1 && d->N1 >= 4 && d->N2 >= 4 && d->N1 % 4 == 0 && d->N2 % 4 == 0, "occ_gemm_tn: N1, N2 must be multiples of 4 (M=%ld N1=%ld N2=%ld)",
+                  (long)d->M, (long)d->N1, (long)d->N2);
+    const long long nseg = d->b_nseg > 1 ? d->b_nseg : 1;
+    const long long seg_len = nseg > 1 ? d->b_seg_len : d->N2;
+    OCC_CHECK_ARG(nseg * seg_len == d->N2 && seg_len % 4 == 0 && (nseg == 1 || d->b_seg_stride % 4 == 0), "occ_gemm_tn: bad B segments");
+    OCC_CHECK_ARG(d->a_map.rows_per_batch >= 1 && d->b_map.rows_per_batch >= 1, "occ_gemm_tn: rows_per_batch must be >= 1");
+    OCC_CHECK_ARG(d->a_map.row_stride % 4 == 0 && d->a_map.batch_stride % 4 == 0 && d->a_map.line_stride % 4 == 0 &&
+                  d->b_map.row_stride % 4 == 0 && d->b_map.batch_stride % 4 == 0 && d->b_map.line_stride % 4 == 0,
+                  "occ_gemm_tn: strides must keep rows 16-byte aligned");
+    OCC_CHECK_ARG(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0 && d->ldc >= d->N2, "occ_gemm_tn: alignment / ldc");
+    TnArgs a;
+    a.M = d->M; a.N1 = d->N1; a.N2 = d->N2;
+    a.A = (const float*)d->A; a.amap = to_rowmap(d->a_map);
+    a.B = (const float*)d->B; a.bmap = to_rowmap(d->b_map); a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->b_seg_stride;
+    a.C = (float*)d->C; a.ldc = d->ldc; a.alpha = d->alpha;
+    const long long t1 = occ_cdiv(d->N1, TT), t2 = occ_cdiv(d->N2, TT);
+    long long split = occ_cdiv(1024, t1 * t2);                       // aim at ~1024 workgroups
+    const long long max_split = occ_cdiv(d->M, 4 * SLAB);            // at least 128 rows each
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    if (split > 65535) split = 65535;
+    a.rows_per_split = occ_cdiv(occ_cdiv(d->M, split), SLAB) * SLAB;
+    split = occ_cdiv(d->M, a.rows_per_split);
+    OCC_CHECK_ARG(t1 < 65536 && t2 < 65536, "occ_gemm_tn: output too large");
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)t1, (unsigned)t2, (unsigned)split), dim3(THREADS), 0, (hipStream_t)stream, a);
+    OCC_LAUNCH_CHECK("occ_gemm_tn");
+    return OCC_OK;
+}
+
+int occ_colsum(const float* A, const occ_rowmap* a_map, int64_t M, int64_t N, float* out, float alpha, void* stream) {
+    OCC_CHECK_ARG(A && a_map && out && M >= 1 && N >= 1 && a_map->rows_per_batch >= 1, "occ_colsum: bad argument");
+    long long split = occ_cdiv(M, 512);
+    if (split > 256) split = 256;
+    const long long rps = occ_cdiv(M, split);
+    split = occ_cdiv(M, rps);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)occ_cdiv(N, 64), (unsigned)split), dim3(THREADS), 0, (hipStream_t)stream, A,
+                       to_rowmap(*a_map), (long long)M, (long long)N, rps, out, alpha);
+    OCC_LAUNCH_CHECK("occ_colsum");
+    return OCC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+"""HIP AASIST back-end (C ABI) vs the reference's own outputs (tests/golden/aasist.npz, produced by
+models/sslassist.py with the fairseq wrapper stubbed) and vs the torch-CPU oracle for train mode with
+injected dropout masks.  Tolerance: 1e-3 (north-star fp32 bar) on O(1) outputs; gradients 2e-3 relative
+to the tensor's max."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+GA = golden("aasist.npz")
+CASES = {"a": (12, 199, 100), "b": (3, 201, 101), "c": (1, 650, 102)}
+
+
+def _r(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _feats(tag):
+    B, T, s = CASES[tag]
+    return torch.randn(B, T, 1024, generator=torch.Generator().manual_seed(s))
+
+
+def _params():
+    from oracle import aasist_ref
+    from oracle.fill import fill_like
+    return fill_like(aasist_ref.param_shapes(), seed=0)
+
+
+# ------------------------------------------------------------------------------- kernel level ---
+@pytest.mark.parametrize("M,N1,N2", [(1000, 64, 64), (88704, 32, 192), (517, 128, 1024), (33, 4, 24), (4096, 2, 160) if False else (4096, 4, 160)])
+def test_gemm_tn_and_colsum(M, N1, N2):
+    from occm_amd import backend_ops as K
+    a, b = _r(M, N1, seed=1), _r(M, N2, seed=2)
+    C = torch.zeros(N1, N2).cuda()
+    K.gemm_tn(M, N1, N2, a.cuda(), K.full(M, N1), b.cuda(), K.full(M, N2), C, N2)
+    ref = a.double().T @ b.double()
+    tol = 2e-6 * float(ref.abs().max()) + 1e-4
+    torch.testing.assert_close(C.cpu().double(), ref, rtol=1e-4, atol=tol)
+    s = torch.zeros(N1).cuda()
+    K.colsum(a.cuda(), K.full(M, N1), M, N1, s)
+    torch.testing.assert_close(s.cpu().double(), a.double().sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_conv2d_2x3_fwd_dgrad_wgrad_as_gemms():
+    """One (2,3) pad (1,1) conv over a zero-bordered channels-last image: forward, input grad, weight grad."""
+    from occm_amd import backend_ops as K, ops
+    B, H, W, ci, co = 2, 42, 66, 32, 64
+    Wp = W + 2
+    x = _r(B, ci, H, W, seed=3).requires_grad_(True)
+    w = _r(co, ci, 2, 3, seed=4, scale=0.1).requires_grad_(True)
+    bias = _r(co, seed=5)
+    y = F.conv2d(x, w, bias, padding=(1, 1))                      # [B,co,43,W]
+    gy = _r(B, co, 43, W, seed=6)
+    y.backward(gy)
+    X = torch.zeros(B, 44, Wp, ci); X[:, 1:43, 1:W + 1] = x.detach().permute(0, 2, 3, 1)
+    X = X.cuda()
+    wi = w.detach().permute(0, 2, 3, 1).contiguous().cuda()       # [co,2,3,ci]
+    R1 = B * 43 * W
+    out = torch.empty(R1, co, device="cuda")
+    amap = ops.rowmap(43 * W, 44 * Wp * ci, ci, W, Wp * ci)
+    ops.gemm_raw(R1, co, 6 * ci, X, amap, wi, 6 * ci, out, ops.rowmap(R1, 0, co), ops.OCC_F32, ops.OCC_F32, bias=bias.cuda(), a_seg=(2, 3 * ci, Wp * ci))
+    torch.testing.assert_close(out.cpu().view(B, 43, W, co).permute(0, 3, 1, 2), y.detach(), rtol=1e-4, atol=1e-4)
+    # weight gradient
+    D1 = torch.zeros(B, 43, Wp, co); D1[:, :, 1:W + 1] = gy.permute(0, 2, 3, 1)
+    D1 = D1.cuda()
+    dmap = ops.rowmap(43 * W, 43 * Wp * co, co, W, Wp * co)
+    gw = torch.zeros(co, 2, 3, ci, device="cuda")
+    K.gemm_tn(R1, co, 6 * ci, D1.data_ptr() + co * 4, dmap, X, amap, gw, 6 * ci, b_seg=(2, 3 * ci, Wp * ci))
+    torch.testing.assert_close(gw.cpu().permute(0, 3, 1, 2), w.grad, rtol=1e-3, atol=1e-3 * float(w.grad.abs().max()))
+    gb = torch.zeros(co, device="cuda")
+    K.colsum(D1.data_ptr() + co * 4, dmap, R1, co, gb)
+    torch.testing.assert_close(gb.cpu(), gy.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    # input gradient: flipped / transposed weights over the padded output gradient
+    wd = torch.empty(ci, 2, 3, co, device="cuda")
+    K.copy_strided(wi, wd, 3 * ci + 2 * ci, (ci, 2, 3, co), (1, -3 * ci, -ci, 6 * ci))
+    R = B * 42 * W
+    gx = torch.empty(R, ci, device="cuda")
+    ops.gemm_raw(R, ci, 6 * co, D1, ops.rowmap(42 * W, 43 * Wp * co, co, W, Wp * co), wd, 6 * co, gx, ops.rowmap(R, 0, ci), ops.OCC_F32, ops.OCC_F32,
+                 a_seg=(2, 3 * co, Wp * co))
+    torch.testing.assert_close(gx.cpu().view(B, 42, W, ci).permute(0, 3, 1, 2), x.grad, rtol=1e-3, atol=1e-3 * float(x.grad.abs().max()))
+
+
+@pytest.mark.parametrize("C,act", [(64, "selu"), (1, "selu"), (128, "none"), (32, "relu")])
+def test_batchnorm_train_fwd_bwd_and_running_stats(C, act):
+    from occm_amd import backend_ops as K
+    from occm_amd._lib import ACT_NONE, ACT_RELU, ACT_SELU
+    code = {"selu": ACT_SELU, "none": ACT_NONE, "relu": ACT_RELU}[act]
+    fn = {"selu": F.selu, "none": lambda t: t, "relu": F.relu}[act]
+    rows = 1777
+    x = (_r(rows, C, seed=7) * 2 + 0.5).requires_grad_(True)
+    g, b = (1 + 0.1 * _r(C, seed=8)).requires_grad_(True), (0.1 * _r(C, seed=9)).requires_grad_(True)
+    rm, rv = 0.1 * _r(C, seed=10), 0.5 + _r(C, seed=11).abs()
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = fn(F.batch_norm(x, rm_ref, rv_ref, g, b, training=True, momentum=0.1, eps=1e-5))
+    gy = _r(rows, C, seed=12)
+    y.backward(gy)
+    dev = lambda t: t.detach().clone().cuda()
+    ws, sums = torch.empty(512 * 256 * 2, dtype=torch.float64, device="cuda"), torch.empty(512, device="cuda")
+    mean, rstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    rmd, rvd, nbt = dev(rm), dev(rv), torch.zeros(1, dtype=torch.int64, device="cuda")
+    xd = dev(x)
+    K.bn_stats(xd, K.full(rows, C), rows, C, ws, mean, rstd, rmd, rvd, nbt, True)
+    out = torch.empty(rows, C, device="cuda")
+    K.bn_act_fwd(xd, K.full(rows, C), mean, rstd, dev(g), dev(b), code, out, K.full(rows, C), rows, C)
+    torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rvd.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
+    assert int(nbt) == 1
+    dx, dg, db = torch.empty(rows, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    K.bn_act_bwd(dev(gy), K.full(rows, C), xd, K.full(rows, C), mean, rstd, dev(g), dev(b), code, dx, K.full(rows, C), dg, db, ws, sums, rows, C)
+    torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(dg.cpu(), g.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_softmax_weighted_sums_fwd_bwd():
+    from occm_amd import backend_ops as K
+    B, H, W, C = 2, 42, 66, 64
+    x = _r(B, C, H, W, seed=13).requires_grad_(True)
+    w = _r(B, C, H, W, seed=14).requires_grad_(True)
+    pos = _r(1, H, C, seed=15)
+    eS = (x * torch.softmax(w, dim=-1)).sum(-1).transpose(1, 2) + pos
+    eT = (x * torch.softmax(w, dim=-2)).sum(-2).transpose(1, 2)
+    gS, gT = _r(B, H, C, seed=16), _r(B, W, C, seed=17)
+    ((eS * gS).sum() + (eT * gT).sum()).backward()
+    cl = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    xc, wc = cl(x), cl(w)
+    oS, oT = torch.empty(B, H, C, device="cuda"), torch.empty(B, W, C, device="cuda")
+    K.softmax_wsum_fwd(xc, wc, B * H, 1, W * C, 0, W, C, C, pos.cuda(), H, oS)
+    K.softmax_wsum_fwd(xc, wc, B * W, W, H * W * C, C, H, W * C, C, None, 1, oT)
+    torch.testing.assert_close(oS.cpu(), eS.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(oT.cpu(), eT.detach(), rtol=1e-4, atol=1e-5)
+    dx, dw = torch.empty_like(xc), torch.empty_like(wc)
+    K.softmax_wsum_bwd(xc, wc, B * H, 1, W * C, 0, W, C, C, gS.cuda(), dx, dw, 0)
+    K.softmax_wsum_bwd(xc, wc, B * W, W, H * W * C, C, H, W * C, C, gT.cuda(), dx, dw, 1)
+    torch.testing.assert_close(dx.cpu().permute(0, 3, 1, 2), x.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(dw.cpu().permute(0, 3, 1, 2), w.grad, rtol=1e-3, atol=1e-5)
+
+
+def test_dropout_mask_statistics_and_reuse():
+    from occm_amd import backend_ops as K
+    x = torch.ones(1 << 18, device="cuda")
+    y, m = torch.empty_like(x), torch.empty(1 << 18, dtype=torch.uint8, device="cuda")
+    K.dropout(x, y, m, 0.3, 11, 5, True)
+    keep = float(m.float().mean())
+    assert abs(keep - 0.7) < 5e-3 and torch.allclose(y, m.float() / 0.7)
+    y2 = torch.empty_like(x)
+    K.dropout(2 * x, y2, m, 0.3, 0, 0, False)
+    assert torch.allclose(y2, 2 * y)
+
+
+# ------------------------------------------------------------------------------- model level ---
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_backend_eval_matches_reference(tag):
+    from occm_amd.models.sslassist import AasistBackend
+    be = AasistBackend(_params())
+    emb, out = be.forward(_feats(tag).cuda(), train=False)
+    np.testing.assert_allclose(emb.cpu().numpy(), GA["eval_emb_" + tag], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(out.cpu().numpy(), GA["eval_out_" + tag], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_backend_train_no_dropout_matches_reference_incl_grads(tag):
+    from occm_amd import ops
+    from occm_amd.models.sslassist import AasistBackend
+    B = CASES[tag][0]
+    be = AasistBackend(_params())
+    be.zero_grad()
+    emb, out = be.forward(_feats(tag).cuda(), train=True, masks={})
+    np.testing.assert_allclose(emb.cpu().numpy(), GA["train_emb_" + tag], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(out.cpu().numpy(), GA["train_out_" + tag], rtol=1e-3, atol=1e-3)
+    labels = (torch.arange(B) % 12 >= 6).long().cuda()
+    lc, demb = ops.compactness_loss(emb, scale=0.1, want_grad=True)
+    ld, dlog = ops.ce_loss(out, labels, scale=0.9, want_grad=True)
+    np.testing.assert_allclose(0.1 * lc.item() + 0.9 * ld.item(), GA["train_loss_" + tag], rtol=1e-4)
+    be.backward(demb, dlog)
+    sd = be.state_dict()
+    for key in GA.files:
+        if key.startswith("rs_%s_" % tag):
+            np.testing.assert_allclose(sd[key[len("rs_%s_" % tag):]].cpu().numpy(), GA[key], rtol=1e-3, atol=1e-5)
+    grads = be.grad_dict()
+    names, norms = list(GA["gradnames_" + tag]), GA["gradnorms_" + tag]
+    bad = []
+    for n, ref in zip(names, norms):
+        got = float(grads[str(n)].norm())
+        if ref < 0:
+            if got != 0.0:
+                bad.append((n, got, ref))
+        elif abs(got - ref) > 3e-3 * ref + 3e-5:
+            bad.append((n, got, ref))
+    assert not bad, bad[:12]
+    for key in GA.files:
+        if key.startswith("grad_%s_" % tag) and "rows0_4" not in key:
+            ref = GA[key]
+            np.testing.assert_allclose(grads[key[len("grad_%s_" % tag):]].cpu().numpy(), ref, rtol=3e-3, atol=max(3e-3 * np.abs(ref).max(), 1e-6))
+    ref = GA["grad_%s_LL.weight_rows0_4" % tag]
+    np.testing.assert_allclose(grads["LL.weight"][:4].cpu().numpy(), ref, rtol=3e-3, atol=3e-3 * np.abs(ref).max())
+
+
+def test_backend_train_with_injected_dropout_masks_matches_oracle():
+    """Train mode WITH dropout: the same keep-masks drive the oracle and the HIP path."""
+    from oracle import aasist_ref, losses_ref
+    from occm_amd import ops
+    from occm_amd.models.sslassist import AasistBackend
+    B, T = 6, 199
+    W = T // 3
+    g = torch.Generator().manual_seed(77)
+    shapes = {"GAT_layer_S": (B, 42, 64), "GAT_layer_T": (B, W, 64), "pool_S": (B, 42, 64), "pool_T": (B, W, 64),
+              "HtrgGAT_layer_ST11": (B, 54, 64), "HtrgGAT_layer_ST21": (B, 54, 64), "HtrgGAT_layer_ST12": (B, 26, 32), "HtrgGAT_layer_ST22": (B, 26, 32),
+              "pool_hS1": (B, 21, 32), "pool_hT1": (B, 33, 32), "pool_hS2": (B, 21, 32), "pool_hT2": (B, 33, 32),
+              "way_T1": (B, 16, 32), "way_T2": (B, 16, 32), "way_S1": (B, 10, 32), "way_S2": (B, 10, 32), "way_M1": (B, 32), "way_M2": (B, 32),
+              "last": (B, 160)}
+    ps = {"GAT": 0.2, "Htr": 0.2, "poo": 0.3, "way": 0.2, "las": 0.5}
+    masks = {k: (torch.rand(s, generator=g) >= ps[k[:3]]).to(torch.uint8) for k, s in shapes.items()}
+    feats = torch.randn(B, T, 1024, generator=g)
+    p = _params()
+    for k, v in p.items():
+        if v.dtype.is_floating_point and not k.split(".")[-1].startswith("running"):
+            v.requires_grad_(True)
+    m_or = {k: (v.unsqueeze(1) if k.startswith("way_M") else v) for k, v in masks.items()}
+    emb_r, out_r = aasist_ref.backend_forward(feats, p, train=True, masks=m_or)
+    labels = (torch.arange(B) % 12 >= 3).long()
+    (0.1 * losses_ref.compactness_loss(emb_r) + 0.9 * losses_ref.descriptiveness_loss(out_r, labels)).backward()
+    be = AasistBackend(_params())
+    be.zero_grad()
+    emb, out = be.forward(feats.cuda(), train=True, masks=masks)
+    torch.testing.assert_close(emb.cpu(), emb_r.detach(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out.cpu(), out_r.detach(), rtol=1e-3, atol=1e-3)
+    assert float((emb == 0).float().mean()) > 0.3            # quirk: the returned emb is the dropped one
+    _, demb = ops.compactness_loss(emb, scale=0.1, want_grad=True)
+    _, dlog = ops.ce_loss(out, labels.cuda(), scale=0.9, want_grad=True)
+    be.backward(demb, dlog)
+    grads = be.grad_dict()
+    bad = []
+    for k, v in p.items():
+        if v.grad is None or k not in grads:
+            continue
+        ref = v.grad
+        err = float((grads[k].cpu() - ref).abs().max())
+        if err > 3e-3 * float(ref.abs().max()) + 2e-6:
+            bad.append((k, err, float(ref.abs().max())))
+    assert not bad, bad[:12]
+
+
+def test_state_dict_round_trip_uses_reference_keys_and_layouts():
+    from oracle import aasist_ref
+    from occm_amd.models.sslassist import AasistBackend
+    p = _params()
+    be = AasistBackend(p)
+    sd = be.state_dict()
+    assert set(sd.keys()) == set(aasist_ref.param_shapes().keys())
+    for k, v in p.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        torch.testing.assert_close(sd[k].cpu().to(v.dtype), v)
