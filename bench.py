@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterances/s of one training step on 4 s @ 16 kHz synthetic utterances.
+
+Workload at N=1 = BASELINE.json configs[1]: XLS-R-300M frozen front-end (bf16 MFMA) + AASIST back-end
+(fwd + loss + bwd + Adam, f32), bs=32 per GPU.  N>1: weak scaling, 32 utterances per rank, one process per GPU
+(torchrun), RCCL all-reduce of the flat back-end gradient.  One JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+L_SAMPLES, BS = 64000, 32
+BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def synth_batch(B, rank, device):
+    g = torch.Generator().manual_seed(1234 + rank)
+    wav = (0.1 * torch.randn(B, L_SAMPLES, generator=g)).clamp(-1, 1)
+    labels = (torch.arange(B) % 12 >= 6).long()              # [0]*6 + [1]*6 groups (oc_training.py:215-240)
+    return wav.to(device), labels.to(device)
+
+
+def gemm_flops_per_utt(cfg, L):
+    """Algorithmic FLOPs of the launches of the bf16 GEMM kernel per utterance (SURVEY.md section 8d formula terms
+    FE (layers 1-6) + PROJ + POS + LIN); layer 0 of the conv stack and attention run in other kernels."""
+    Ts, Lc = [], L
+    for k, s in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
+        Lc = (Lc - k) // s + 1
+        Ts.append(Lc)
+    C, T, d, f, n = 512, Ts[-1], cfg.dim, cfg.ffn, cfg.layers
+    fe = 2 * (sum(Ts[1:5]) * C * C * 3 + sum(Ts[5:7]) * C * C * 2)
+    proj = 2 * T * C * d
+    pos = 2 * (T + 1) * d * (d // cfg.pos_groups) * cfg.pos_k
+    lin = 2 * T * (4 * d * d + 2 * d * f) * n
+    return fe + proj + pos + lin
+
+
+def cpu_baseline(budget_s=25.0):
+    """The torch-CPU oracle (kind "port": the reference's fairseq front-end cannot run) on a bounded sample of the same
+    workload: frozen XLS-R-300M forward + AASIST fwd/bwd + Adam, bs=2, as many steps as fit the budget (>= 1)."""
+    from oracle import aasist_ref, losses_ref, xlsr_ref
+    from oracle.fill import fill_like
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = xlsr_ref.XlsrConfig.xlsr_300m()
+    px = fill_like(xlsr_ref.param_shapes(cfg), seed=0)
+    pb = fill_like(aasist_ref.param_shapes(), seed=0)
+    train = [v.requires_grad_(True) for k, v in pb.items() if v.dtype.is_floating_point and not k.split(".")[-1].startswith("running")]
+    opt = torch.optim.Adam(train, lr=1e-5)
+    B = 2
+    wav, labels = synth_batch(B, 0, "cpu")
+    t0 = time.time()
+    steps = 0
+    while steps < 1 or (time.time() - t0) < budget_s * 0.6:
+        with torch.no_grad():
+            feats = xlsr_ref.extract_feat(wav, px, cfg)
+        opt.zero_grad()
+        emb, out = aasist_ref.backend_forward(feats, pb, train=True)
+        loss = 0.0 * losses_ref.compactness_loss(emb) + 1.0 * losses_ref.descriptiveness_loss(out, labels)
+        loss.backward()
+        opt.step()
+        steps += 1
+    dt = time.time() - t0
+    return {"value": round(B * steps / dt, 4), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": "%d step(s) of bs=%d, fp32 torch-CPU oracle (XLS-R-300M frozen fwd + AASIST fwd/bwd + Adam), %d threads" % (steps, B, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the frozen front-end from a HIP graph")
+    args = ap.parse_args()
+
+    from occm_amd import ops, parallel
+    from occm_amd._lib import require_gpu
+    from occm_amd.models import xlsr
+    from occm_amd.models.sslassist import AModel
+    from occm_amd.trainer import OcTrainer
+    require_gpu()
+    rank, world, local = parallel.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = xlsr.XlsrConfig.xlsr_300m()
+    model = AModel(None, dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, seed=0)
+    model.train()
+    trainer = OcTrainer(model, lr=1e-5, w_compact=0.0, w_descr=1.0)
+    wav, labels = synth_batch(BS, rank, dev)
+    fe = model.ssl_model.model
+
+    # The frozen front-end is a fixed launch sequence: capture it once into a HIP graph (launch-bound otherwise).
+    graph = None
+    if not args.no_graph:
+        static_wav = wav.clone()
+        fe.forward(static_wav, out_dtype=torch.float32)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_feats = fe.forward(static_wav, out_dtype=torch.float32)
+        orig_forward = fe.forward
+
+        def replay_forward(w, out_dtype=None, taps=None):
+            static_wav.copy_(w)
+            graph.replay()
+            return static_feats
+        fe.forward = replay_forward
+
+    for _ in range(args.warmup):
+        trainer.step(wav, labels)
+    parallel.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(wav, labels)
+    torch.cuda.synchronize(); parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    lc, ld = trainer.last
+    loss_d = float(ld.item())
+
+    # ---- roofline of the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / measured launch time ----
+    roof = None
+    if rank == 0:
+        if graph is not None:
+            fe.forward = orig_forward
+        ops.PROFILE = []
+        for _ in range(3):
+            fe.forward(wav, out_dtype=torch.float32)
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        t_ms = sum(a.elapsed_time(b) for kind, a, b in recs if kind == "gemm_bf16") / 3.0
+        n_launch = sum(1 for kind, _, _ in recs if kind == "gemm_bf16") // 3
+        fl = gemm_flops_per_utt(cfg, L_SAMPLES) * BS
+        ach = fl / (t_ms * 1e-3) / 1e12
+        roof = {"kernel": "gemm_kernel<bf16> (all front-end Linear/Conv1d launches of one step)", "bound": "mfma",
+                "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
+                "traffic": None, "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / max(n_launch, 1), 2),
+                "flops_per_step": fl}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+    if rank == 0:
+        out = {"metric": "utterances/sec (4 s @16 kHz) training step", "value": round(BS * world * args.steps / dt, 2), "unit": "utterances/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "XLSR-300M frozen frontend + AASIST backend, bs=32 per GPU, 64000-sample utterances (BASELINE configs[1])",
+                          "global_batch": BS * world, "samples_per_utt": L_SAMPLES, "parallelism": "dp%d" % world,
+                          "frontend": "bf16 MFMA, f32 accumulate, HIP-graph replay", "backend": "f32 MFMA fwd+bwd, dropout on, Adam lr=1e-5",
+                          "loss": "0.0*compactness + 1.0*descriptiveness (oc_training.py:380-381)", "final_loss_d": round(loss_d, 5)},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

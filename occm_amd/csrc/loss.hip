@@ -21,27 +21,28 @@ __global__ __launch_bounds__(LOSS_THREADS) void compactness_kernel(const float* 
                                                                   float* __restrict__ demb, int n_groups, int group, int E, float scale) {
     __shared__ float red[4];
     __shared__ float inv_dist[6];
-    const int NB = 6;                                    // custom_loss.py:15
+    constexpr int NBMAX = 6;                             // custom_loss.py:15: batch_embeddings[:6]
+    const int NB = group < NBMAX ? group : NBMAX;        // a shorter batch simply has fewer rows
     float total = 0.f;
     for (int g = 0; g < n_groups; ++g) {
         const float* e = emb + (size_t)g * group * E;
-        float d2[NB] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float d2[NBMAX] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c = threadIdx.x; c < E; c += LOSS_THREADS) {
-            float v[NB], S = 0.f;
+            float v[NBMAX], S = 0.f;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) { v[i] = e[(size_t)i * E + c]; S += v[i]; }
+            for (int i = 0; i < NBMAX; ++i) { v[i] = i < NB ? e[(size_t)i * E + c] : 0.f; S += v[i]; }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
+            for (int i = 0; i < NBMAX; ++i) {
                 const float u = v[i] - (S - v[i]) / (float)(NB - 1) + PAIR_EPS;
-                d2[i] += u * u;
+                if (i < NB) d2[i] += u * u;
             }
         }
         float gl = 0.f;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
+        for (int i = 0; i < NBMAX; ++i) {
             const float dist = sqrtf(block_sum_256(d2[i], red));
-            gl += dist;
-            if (threadIdx.x == 0) inv_dist[i] = dist > 0.f ? 1.f / dist : 0.f;
+            if (i < NB) gl += dist;
+            if (threadIdx.x == 0) inv_dist[i] = (i < NB && dist > 0.f) ? 1.f / dist : 0.f;
         }
         total += gl / (float)NB;
         if (demb) {
@@ -49,17 +50,17 @@ __global__ __launch_bounds__(LOSS_THREADS) void compactness_kernel(const float* 
             float* de = demb + (size_t)g * group * E;
             const float k = scale / ((float)NB * (float)n_groups);
             for (int c = threadIdx.x; c < E; c += LOSS_THREADS) {
-                float v[NB], S = 0.f, uh[NB], uh_sum = 0.f;
+                float v[NBMAX], S = 0.f, uh[NBMAX], uh_sum = 0.f;
 #pragma unroll
-                for (int i = 0; i < NB; ++i) { v[i] = e[(size_t)i * E + c]; S += v[i]; }
+                for (int i = 0; i < NBMAX; ++i) { v[i] = i < NB ? e[(size_t)i * E + c] : 0.f; S += v[i]; }
 #pragma unroll
-                for (int i = 0; i < NB; ++i) {
+                for (int i = 0; i < NBMAX; ++i) {
                     uh[i] = (v[i] - (S - v[i]) / (float)(NB - 1) + PAIR_EPS) * inv_dist[i];
                     uh_sum += uh[i];
                 }
 #pragma unroll
-                for (int i = 0; i < NB; ++i)
-                    de[(size_t)i * E + c] = k * ((float)NB / (float)(NB - 1) * uh[i] - uh_sum / (float)(NB - 1));
+                for (int i = 0; i < NBMAX; ++i)
+                    if (i < NB) de[(size_t)i * E + c] = k * ((float)NB / (float)(NB - 1) * uh[i] - uh_sum / (float)(NB - 1));
                 for (int i = NB; i < group; ++i) de[(size_t)i * E + c] = 0.f;
             }
             __syncthreads();
@@ -139,7 +140,7 @@ extern "C" {
 
 int occ_compactness_loss(const float* emb, float* loss, float* demb, int64_t n_groups, int64_t group, int64_t E, float scale, void* stream) {
     OCC_CHECK_ARG(emb && loss, "occ_compactness_loss: null pointer");
-    OCC_CHECK_ARG(n_groups >= 1 && group >= 6 && E >= 1, "occ_compactness_loss: needs n_groups>=1, group>=6 (got %ld, %ld)", (long)n_groups, (long)group);
+    OCC_CHECK_ARG(n_groups >= 1 && group >= 2 && E >= 1, "occ_compactness_loss: needs n_groups>=1, group>=2 (got %ld, %ld)", (long)n_groups, (long)group);
     hipLaunchKernelGGL(compactness_kernel, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, emb, loss, demb, (int)n_groups, (int)group, (int)E, scale);
     OCC_LAUNCH_CHECK("occ_compactness_loss");
     return OCC_OK;

@@ -19,6 +19,10 @@ def _dev(t):
     return t
 
 
+# bench.py sets this to a list to time individual launches with events on the launch stream: (kind, start, end)
+PROFILE = None
+
+
 def rowmap(rows_per_batch, batch_stride, row_stride, rows_per_line=0, line_stride=0):
     return RowMap(int(rows_per_batch), int(batch_stride), int(row_stride), int(rows_per_line), int(line_stride))
 
@@ -49,6 +53,13 @@ def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, 
     d.alpha = float(alpha)
     if groups is not None:
         d.n_groups, d.a_group_stride, d.w_group_stride, d.c_group_stride = [int(v) for v in groups]
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().occ_gemm(ctypes.byref(d), stream_ptr()), "occ_gemm")
+        e1.record()
+        PROFILE.append(("gemm_bf16" if ab_dtype == OCC_BF16 else "gemm_f32", e0, e1))
+        return
     check(lib().occ_gemm(ctypes.byref(d), stream_ptr()), "occ_gemm")
 
 
