@@ -49,7 +49,10 @@ def cpu_baseline(budget_s=25.0):
     workload: frozen XLS-R-300M forward + AASIST fwd/bwd + Adam, bs=2, as many steps as fit the budget (>= 1)."""
     from oracle import aasist_ref, losses_ref, xlsr_ref
     from oracle.fill import fill_like
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))         # the cores this job may actually use (a 1-GPU box exposes a share)
+    except AttributeError:
+        cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     cfg = xlsr_ref.XlsrConfig.xlsr_300m()
     px = fill_like(xlsr_ref.param_shapes(cfg), seed=0)

@@ -1,0 +1,124 @@
+"""Host-side mirrors of the reference surface (no GPU): datasets, protocol parsing, EER, CLI plumbing."""
+import os
+import random
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden, synth_wave
+
+
+def _write_wav(path, n, seed):
+    x = (np.clip(synth_wave(seed, n), -1, 1) * 32767).astype(np.int16)
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.tobytes())
+
+
+def test_genspoof_list_and_pad_match_reference_vectors():
+    from occm_amd.data_utils_SSL import genSpoof_list, pad
+    G = golden("protocol.npz")
+    d, l = genSpoof_list(os.path.join(GOLDEN, "protocol_train.txt"), is_train=True)
+    assert l == list(G["keys"]) and [d[k] for k in l] == list(G["labels"])
+    assert genSpoof_list(os.path.join(GOLDEN, "protocol_train.txt"), is_eval=True)[0].startswith("LA_0079")
+    R = golden("rawboost.npz")
+    np.testing.assert_array_equal(pad(synth_wave(3, 1000), 2600), R["pad_short"])
+    np.testing.assert_array_equal(pad(synth_wave(3, 3000), 2600), R["pad_long"])
+
+
+def test_evaluate_metrics_match_reference_vectors():
+    from occm_amd.evaluate_metrics import calculate_confusion_matrix, compute_eer
+    G = golden("losses_eer.npz")
+    for seed in range(3):
+        rs = np.random.RandomState(seed)
+        tar, non = rs.randn(700) + 1.0, rs.randn(1300) - 0.5
+        if seed == 2:
+            tar, non = np.round(tar, 1), np.round(non, 1)
+        eer, thr = compute_eer(tar, non)
+        np.testing.assert_allclose([eer, thr], G["eer_%d" % seed], rtol=0, atol=0)
+        np.testing.assert_array_equal(np.array(calculate_confusion_matrix(tar, non, thr)), G["conf_%d" % seed])
+
+
+def test_calculate_eer_cli_function(tmp_path):
+    from occm_amd.calculate_eer import calculate_EER
+    from occm_amd.evaluate_metrics import compute_eer
+    rs = np.random.RandomState(0)
+    prot, sc, bona, spoof = [], [], [], []
+    for i in range(200):
+        lab = "bonafide" if i % 3 == 0 else "spoof"
+        s = rs.randn() + (1.0 if lab == "bonafide" else -1.0)
+        prot.append(f"LA_{i:04d} utt{i} - A01 {lab}"); sc.append(f"utt{i} {s}")
+        (bona if lab == "bonafide" else spoof).append(s)
+    (tmp_path / "p.txt").write_text("\n".join(prot) + "\n"); (tmp_path / "s.txt").write_text("\n".join(sc) + "\n")
+    eer, thr = calculate_EER(str(tmp_path / "p.txt"), str(tmp_path / "s.txt"), verbose=False)
+    ref = compute_eer(np.array([float(x) for x in map(str, bona)]), np.array(spoof))
+    assert abs(eer - ref[0]) < 1e-12
+
+
+def test_pfdataset_group_layout(tmp_path):
+    """6 bona fide + 1 spoof + 5 vocoded, labels [0]*6+[1]*6, zero padding to the longest (oc_training.py:201-256)."""
+    from occm_amd.oc_training import PFDataset, VOCODERS
+    d, v = tmp_path / "wav", tmp_path / "voc"
+    d.mkdir(); v.mkdir()
+    lines = []
+    for i in range(8):
+        lines.append(f"LA_00{i} B{i} - - bonafide"); _write_wav(str(d / f"B{i}.wav"), 600 + 37 * i, i)
+    for i in range(3):
+        lines.append(f"LA_01{i} S{i} - A0{i} spoof"); _write_wav(str(d / f"S{i}.wav"), 900 + 11 * i, 50 + i)
+    for i in range(8):
+        for k, name in enumerate(VOCODERS):
+            _write_wav(str(v / f"{name}_B{i}.wav"), 1200 + k, 100 + i * 5 + k)
+    (tmp_path / "prot.txt").write_text("\n".join(lines) + "\n")
+    ds = PFDataset(str(tmp_path / "prot.txt"), str(d), vocoded_dir=str(v))
+    assert len(ds) == 8
+    random.seed(0)
+    x, y = ds[2]
+    assert x.shape[0] == 12 and y.tolist() == [0] * 6 + [1] * 6 and x.dtype == torch.float32 and y.dtype == torch.int64
+    assert x.shape[1] == 1204                                     # longest member is a vocoded file
+    first = ds._load(str(d / "B2.wav"))[0]
+    np.testing.assert_array_equal(x[0, : first.shape[0]].numpy(), first)     # bona1 = indexed file, sorted keys first
+    assert float(x[0, first.shape[0]:].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        ds._get_random_files([1, 2], None, 5)
+
+
+def test_asvdataset_modes(tmp_path):
+    from occm_amd.oc_classifier import ASVDataset
+    d = tmp_path / "a"; d.mkdir()
+    _write_wav(str(d / "U1.wav"), 500, 1); _write_wav(str(d / "U2.wav"), 700, 2); _write_wav(str(d / "U3.wav"), 600, 3)
+    (tmp_path / "tr.txt").write_text("LA_1 U1 - - bonafide\nLA_2 U2 - A01 spoof\nLA_3 U3 - - bonafide\n")
+    (tmp_path / "ev.txt").write_text("U2\nU1\n")
+    tr = ASVDataset(str(tmp_path / "tr.txt"), str(d))
+    ev = ASVDataset(str(tmp_path / "ev.txt"), str(d), eval=True)
+    assert tr.file_list == ["U1", "U3"] and len(ev) == 2 and ev.file_list == ["U2", "U1"]
+    x, y = tr[1]
+    assert x.shape == (600,) and y.tolist() == [0]
+
+
+def test_rawboost_flag_defaults_match_reference():
+    from occm_amd.oc_training import rawboost_args
+    a = rawboost_args()
+    assert (a.algo, a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff, a.maxCoeff, a.minG, a.maxG) == (3, 5, 20, 8000, 100, 1000, 10, 100, 0, 0)
+    assert (a.minBiasLinNonLin, a.maxBiasLinNonLin, a.N_f, a.P, a.g_sd, a.SNRmin, a.SNRmax) == (5, 20, 5, 10, 2, 10, 40)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: no module under occm_amd/ may import it."""
+    import re
+    root = os.path.join(os.path.dirname(GOLDEN), "..", "occm_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_ops_fail_loudly_without_gpu():
+    from occm_amd import _lib, ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.OccError):
+        _lib.require_gpu()
+    with pytest.raises(_lib.OccError):
+        ops.linear(torch.zeros(4, 8), torch.zeros(4, 8))
