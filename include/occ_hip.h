@@ -121,6 +121,7 @@ typedef struct occ_gemm_tn_desc {
     const void* B; occ_rowmap b_map; int64_t b_nseg, b_seg_len, b_seg_stride;
     void* C; int64_t ldc;
     float alpha;
+    void* colsum;                      /* optional f32 [N1]: += alpha * column sums of A (the bias gradient), or NULL */
 } occ_gemm_tn_desc;
 int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream);
 /* out[n] += alpha * sum_m A[m,n] (bias gradients).                                                   */

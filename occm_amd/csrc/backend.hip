@@ -159,15 +159,18 @@ __global__ __launch_bounds__(BT) void bn_partial_kernel(const float* __restrict_
         ws[((size_t)blockIdx.x * C + threadIdx.x) * 2 + 1] = q;
     }
 }
-// mean/rstd from the partials (train) or from the running statistics (eval); running stats updated in train mode
-__global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunk, int C, long long rows, float* __restrict__ mean, float* __restrict__ rstd,
-                                   float* __restrict__ run_mean, float* __restrict__ run_var, long long* __restrict__ nbt, float momentum,
-                                   float eps, int train) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// mean/rstd from the partials (train) or from the running statistics (eval); running stats updated in train mode.
+// One wave per channel: lanes stride over the chunks, then a wave reduction.
+__global__ __launch_bounds__(BT) void bn_finalize_kernel(const double* __restrict__ ws, int nchunk, int C, long long rows, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                         long long* __restrict__ nbt, float momentum, float eps, int train) {
+    const int c = blockIdx.x * (BT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     if (train) {
         double s = 0.0, q = 0.0;
-        for (int k = 0; k < nchunk; ++k) { s += ws[((size_t)k * C + c) * 2]; q += ws[((size_t)k * C + c) * 2 + 1]; }
+        for (int k = lane; k < nchunk; k += 64) { s += ws[((size_t)k * C + c) * 2]; q += ws[((size_t)k * C + c) * 2 + 1]; }
+        s = wave_sum(s); q = wave_sum(q);
+        if (lane != 0) return;
         const double m = s / (double)rows;
         double var = q / (double)rows - m * m;
         if (var < 0.0) var = 0.0;
@@ -178,7 +181,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunk, in
             run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
         }
         if (nbt && c == 0) nbt[0] += 1;
-    } else {
+    } else if (lane == 0) {
         mean[c] = run_mean[c];
         rstd[c] = 1.0f / sqrtf(run_var[c] + eps);
     }
@@ -224,13 +227,15 @@ __global__ __launch_bounds__(BT) void bn_bwd_partial_kernel(const float* __restr
         ws[((size_t)blockIdx.x * C + threadIdx.x) * 2 + 1] = q;
     }
 }
-// sums[c] = {sum dz, sum dz*xhat}; dgamma/dbeta accumulated
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunk, int C, float* __restrict__ sums, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// sums[c] = {sum dz, sum dz*xhat}; dgamma/dbeta accumulated.  One wave per channel.
+__global__ __launch_bounds__(BT) void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunk, int C, float* __restrict__ sums,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * (BT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < nchunk; ++k) { s += ws[((size_t)k * C + c) * 2]; q += ws[((size_t)k * C + c) * 2 + 1]; }
+    for (int k = lane; k < nchunk; k += 64) { s += ws[((size_t)k * C + c) * 2]; q += ws[((size_t)k * C + c) * 2 + 1]; }
+    s = wave_sum(s); q = wave_sum(q);
+    if (lane != 0) return;
     sums[2 * c] = (float)s; sums[2 * c + 1] = (float)q;
     if (dgamma) dgamma[c] += (float)q;
     if (dbeta) dbeta[c] += (float)s;
@@ -853,7 +858,7 @@ int occ_bn_stats(const float* x, const occ_rowmap* x_map, int64_t rows, int64_t 
         long long rpc; nchunk = bn_chunks(rows, &rpc);
         hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk), dim3(BT), 0, s, x, to_rowmap(*x_map), (long long)rows, (int)C, rpc, ws);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)occ_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, nchunk, (int)C, (long long)rows, mean, rstd,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)occ_cdiv(C, BT / 64)), dim3(BT), 0, s, (const double*)ws, nchunk, (int)C, (long long)rows, mean, rstd,
                        running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, train);
     OCC_LAUNCH_CHECK("occ_bn_stats");
     return OCC_OK;
@@ -882,7 +887,7 @@ int occ_bn_act_bwd(const float* dy, const occ_rowmap* dy_map, const float* x, co
     const dim3 grid(grid_for(rows * C)), block(BT);
 #define OCC_BN_BWD(A)                                                                                                                      \
     hipLaunchKernelGGL(bn_bwd_partial_kernel<A>, dim3(nchunk), block, 0, s, dy, dym, x, xm, mean, rstd, gamma, beta, (long long)rows, (int)C, rpc, ws); \
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, nchunk, (int)C, sums, dgamma, dbeta); \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(C, BT / 64)), dim3(BT), 0, s, (const double*)ws, nchunk, (int)C, sums, dgamma, dbeta); \
     hipLaunchKernelGGL(bn_bwd_apply_kernel<A>, grid, block, 0, s, dy, dym, x, xm, mean, rstd, gamma, beta, (const float*)sums, dx, dxm, (long long)rows, (int)C)
     if (act == OCC_ACT_SELU) { OCC_BN_BWD(OCC_ACT_SELU); }
     else if (act == OCC_ACT_RELU) { OCC_BN_BWD(OCC_ACT_RELU); }

@@ -13,6 +13,7 @@
 // bf16 inputs use v_mfma_f32_16x16x32_bf16 (f32 accumulate); f32 inputs use the exact-f32
 // v_mfma_f32_16x16x4_f32 with the k index permuted identically on both operands.
 #include "occ_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,6 +43,52 @@ __device__ __forceinline__ float act_rt(int act, float v) {
         case OCC_ACT_RELU: return v > 0.f ? v : 0.f;
         case OCC_ACT_TANH: return tanhf(v);
         default: return v;
+    }
+}
+
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][4], long long m0, long long n0, int wm, int wn, int fr, int fq,
+                                              long long cshift) {
+    // ---- epilogue: lane owns C[m][n..n+3]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long m = m0 + wm * 64 + j * 16 + fr;
+        if (m >= a.M) continue;
+        const long long coff = row_off(a.cmap, m) + cshift;
+        const long long roff = a.R ? row_off(a.rmap, m) + cshift : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long n = n0 + wn * 64 + i * 16 + fq * 4;
+            if (n >= a.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * a.alpha;
+            if (a.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + cshift + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            if (a.act != OCC_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_rt(a.act, v[e]);
+            }
+            if (a.R) {
+                if (a.r_dtype == OCC_F32) {
+                    const float4 rv = *reinterpret_cast<const float4*>(a.R + (roff + n) * 4);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                } else {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(a.R + (roff + n) * 2);
+                    v[0] += bf16_bits_to_f32((unsigned short)(rv.x & 0xffff)); v[1] += bf16_bits_to_f32((unsigned short)(rv.x >> 16));
+                    v[2] += bf16_bits_to_f32((unsigned short)(rv.y & 0xffff)); v[3] += bf16_bits_to_f32((unsigned short)(rv.y >> 16));
+                }
+            }
+            if (a.c_dtype == OCC_F32) {
+                *reinterpret_cast<float4*>(a.C + (coff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2*>(a.C + (coff + n) * 2) = o;
+            }
+        }
     }
 }
 
@@ -150,48 +197,87 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns C[m][n..n+3]
+    gemm_epilogue(a, acc, m0, n0, wm, wn, fr, fq, cshift);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 fast path (K % 64 == 0): same 128x128 tile and fragment layout, but the slab goes global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write), ONE 32 KiB LDS buffer and <= 128
+// VGPRs, so 4 workgroups share a CU and hide each other's load latency (occupancy does the pipelining).
+// The LDS image must be lane-linear per wave-instruction, so the XOR swizzle is applied to the per-lane
+// SOURCE chunk instead: LDS[row][p] = G[row][p ^ (row & 7)]  <=>  chunk c of a row sits at p = c ^ (row & 7).
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__global__ __launch_bounds__(THREADS, 4) void gemm_bf16_dma_kernel(const GemmArgs a) {
+    constexpr int ES = 2, CE = 8, SLAB_K = 64;
+    __shared__ uint4 lds[2][TM * CHUNKS];       // [X|W][row*8 + position]
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    const long long m0 = (long long)tile_m * TM, n0 = (long long)tile_n * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const long long grp = blockIdx.y;
+    const char* Xg = a.X + grp * a.a_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const long long cshift = grp * a.c_gstride;
+
+    // staging: wave-instruction i of wave `wave` fills rows 8*wave + 32*i .. +7 (1 KiB, lane-linear)
+    const int pos = tid & 7, srow = tid >> 3;
+    const char* xsrc[4]; const char* wsrc[4];
+    int csrc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long long m = m0 + wm * 64 + j * 16 + fr;
-        if (m >= a.M) continue;
-        const long long coff = row_off(a.cmap, m) + cshift;
-        const long long roff = a.R ? row_off(a.rmap, m) + cshift : 0;
+    for (int i = 0; i < 4; ++i) {
+        const int row = srow + 32 * i;
+        long long m = m0 + row; if (m > a.M - 1) m = a.M - 1;
+        long long n = n0 + row; if (n > a.N - 1) n = a.N - 1;
+        xsrc[i] = Xg + row_off(a.xmap, m) * ES;
+        wsrc[i] = Wg + n * a.ldw * ES;
+        csrc[i] = pos ^ (row & 7);              // source chunk of this lane
+    }
+    const int nslab = (int)(a.K / SLAB_K);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int slab = 0; slab < nslab; ++slab) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long long n = n0 + wn * 64 + i * 16 + fq * 4;
-            if (n >= a.N) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * a.alpha;
-            if (a.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + cshift + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            if (a.act != OCC_ACT_NONE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_rt(a.act, v[e]);
-            }
-            if (a.R) {
-                if (a.r_dtype == OCC_F32) {
-                    const float4 rv = *reinterpret_cast<const float4*>(a.R + (roff + n) * 4);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                } else {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(a.R + (roff + n) * 2);
-                    v[0] += bf16_bits_to_f32((unsigned short)(rv.x & 0xffff)); v[1] += bf16_bits_to_f32((unsigned short)(rv.x >> 16));
-                    v[2] += bf16_bits_to_f32((unsigned short)(rv.y & 0xffff)); v[3] += bf16_bits_to_f32((unsigned short)(rv.y >> 16));
-                }
-            }
-            if (a.c_dtype == OCC_F32) {
-                *reinterpret_cast<float4*>(a.C + (coff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                uint2 o;
-                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-                *reinterpret_cast<uint2*>(a.C + (coff + n) * 2) = o;
-            }
+            const long long k0 = (long long)slab * SLAB_K + csrc[i] * CE;
+            long long kx = k0;
+            if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
+            const int base = (wave * 8 + 32 * i) * CHUNKS;          // wave-uniform LDS row block
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx * ES), (lds_void*)&lds[0][base], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + k0 * ES), (lds_void*)&lds[1][base], 16, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 wf[4], xf[4];
+            const int chk = kb * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = wn * 64 + i * 16 + fr;
+                wf[i] = lds[1][rw * CHUNKS + (chk ^ (rw & 7))];
+                const int rx = wm * 64 + i * 16 + fr;
+                xf[i] = lds[0][rx * CHUNKS + (chk ^ (rx & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
     }
+    gemm_epilogue(a, acc, m0, n0, wm, wn, fr, fq, cshift);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -237,7 +323,10 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     const long long total = (long long)a.nbm * a.nbn;
     OCC_CHECK_ARG(total < (1ll << 30), "occ_gemm: too many tiles");
     hipStream_t s = (hipStream_t)stream;
-    if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<true>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    static const int variant = getenv("OCC_GEMM_VARIANT") ? atoi(getenv("OCC_GEMM_VARIANT")) : 1;
+    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 1)
+        hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    else if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<true>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else hipLaunchKernelGGL(gemm_kernel<false>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     OCC_LAUNCH_CHECK("occ_gemm");
     return OCC_OK;

@@ -23,6 +23,7 @@ struct TnArgs {
     float* C; long long ldc;
     long long rows_per_split;
     float alpha;
+    float* colsum;            // optional: colsum[n1] += alpha * sum_m A[m, n1] (bias gradient), done by the n2-tile-0 workgroups
 };
 
 __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long long m0 = m_begin; m0 < m_end; m0 += SLAB) {
         float4 va[2], vb[2];
 #pragma unroll
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
                 if (b_ok) vb[i] = *reinterpret_cast<const float4*>(a.B + row_off(a.bmap, m) + bseg_off);
             }
         }
+        csum.x += va[0].x + va[1].x; csum.y += va[0].y + va[1].y; csum.z += va[0].z + va[1].z; csum.w += va[0].w + va[1].w;
         __syncthreads();                                   // previous slab fully consumed
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -77,6 +80,17 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (a.colsum && blockIdx.y == 0) {                     // bias gradient: reduce the 16 row-groups through LDS
+        __syncthreads();
+        *reinterpret_cast<float4*>(&As[srow * LDS_STRIDE + c4 * 4]) = csum;
+        __syncthreads();
+        if (tid < TT && n1_0 + tid < a.N1) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += As[r * LDS_STRIDE + tid];
+            atomicAdd(a.colsum + n1_0 + tid, s * a.alpha);
         }
     }
     // D[row = n1 (A index)][col = n2]: lane holds col fr, rows 4g + r
@@ -130,7 +144,7 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
     a.M = d->M; a.N1 = d->N1; a.N2 = d->N2;
     a.A = (const float*)d->A; a.amap = to_rowmap(d->a_map);
     a.B = (const float*)d->B; a.bmap = to_rowmap(d->b_map); a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->b_seg_stride;
-    a.C = (float*)d->C; a.ldc = d->ldc; a.alpha = d->alpha;
+    a.C = (float*)d->C; a.ldc = d->ldc; a.alpha = d->alpha; a.colsum = (float*)d->colsum;
     const long long t1 = occ_cdiv(d->N1, TT), t2 = occ_cdiv(d->N2, TT);
     long long split = occ_cdiv(1024, t1 * t2);                       // aim at ~1024 workgroups
     const long long max_split = occ_cdiv(d->M, 4 * SLAB);            // at least 128 rows each

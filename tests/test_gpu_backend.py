@@ -47,6 +47,10 @@ def test_gemm_tn_and_colsum(M, N1, N2):
     s = torch.zeros(N1).cuda()
     K.colsum(a.cuda(), K.full(M, N1), M, N1, s)
     torch.testing.assert_close(s.cpu().double(), a.double().sum(0), rtol=1e-4, atol=1e-3)
+    C2, s2 = torch.zeros(N1, N2).cuda(), torch.zeros(N1).cuda()         # bias gradient fused into the same launch
+    K.gemm_tn(M, N1, N2, a.cuda(), K.full(M, N1), b.cuda(), K.full(M, N2), C2, N2, colsum_out=s2)
+    torch.testing.assert_close(C2.cpu().double(), ref, rtol=1e-4, atol=tol)
+    torch.testing.assert_close(s2.cpu().double(), a.double().sum(0), rtol=1e-4, atol=1e-3)
 
 
 def test_conv2d_2x3_fwd_dgrad_wgrad_as_gemms():
