@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 enum occ_status { OCC_OK = 0, OCC_EINVAL = -1, OCC_ELAUNCH = -2, OCC_EUNSUPPORTED = -3 };
-enum occ_dtype { OCC_F32 = 0, OCC_BF16 = 1, OCC_F64 = 2 };
+enum occ_dtype { OCC_F32 = 0, OCC_BF16 = 1, OCC_F64 = 2, OCC_F32_AS_BF16 = 3 /* occ_gemm ab_dtype only: f32 operands in memory, rounded to bf16 on the way into LDS, bf16 MFMA */ };
 enum occ_act { OCC_ACT_NONE = 0, OCC_ACT_GELU = 1, OCC_ACT_SELU = 2, OCC_ACT_RELU = 3, OCC_ACT_TANH = 4 };
 
 const char* occ_last_error(void);
@@ -100,7 +100,7 @@ typedef struct occ_gemm_desc {
     const void* bias;                          /* f32 [N] or NULL */
     const void* R; occ_rowmap r_map; int r_dtype;   /* residual added after activation, or NULL */
     void* C; occ_rowmap c_map; int c_dtype;
-    int ab_dtype;                              /* OCC_BF16: bf16 MFMA (f32 accumulate); OCC_F32: f32 MFMA */
+    int ab_dtype;                              /* OCC_BF16: bf16 MFMA (f32 accumulate); OCC_F32: exact f32 MFMA; OCC_F32_AS_BF16 */
     int act;                                   /* occ_act applied to (acc + bias) */
     float alpha;                               /* acc scaled by alpha before bias */
     /* grouped problems (grouped Conv1d): group g uses A + g*a_group_stride, W + g*w_group_stride and

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "occ_hip.h")
 
-OCC_F32, OCC_BF16, OCC_F64 = 0, 1, 2
+OCC_F32, OCC_BF16, OCC_F64, OCC_F32_AS_BF16 = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_SELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
 
 

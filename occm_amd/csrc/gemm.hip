@@ -92,11 +92,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
     }
 }
 
-template <bool BF16>
+// MODE 0: f32 operands, exact-f32 MFMA.  MODE 1: bf16 operands, bf16 MFMA.  MODE 2: f32 operands in memory, rounded to
+// bf16 while they are staged into LDS, bf16 MFMA (f32 accumulate) -- the back-end's "bf16 compute" mode, which
+// needs no bf16 copies of f32 activations / gradients.
+__device__ __forceinline__ uint4 pack_bf16x8(const float4 lo, const float4 hi) {
+    return make_uint4((unsigned)f32_to_bf16_bits(lo.x) | ((unsigned)f32_to_bf16_bits(lo.y) << 16),
+                      (unsigned)f32_to_bf16_bits(lo.z) | ((unsigned)f32_to_bf16_bits(lo.w) << 16),
+                      (unsigned)f32_to_bf16_bits(hi.x) | ((unsigned)f32_to_bf16_bits(hi.y) << 16),
+                      (unsigned)f32_to_bf16_bits(hi.z) | ((unsigned)f32_to_bf16_bits(hi.w) << 16));
+}
+
+template <int MODE>
 __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
-    constexpr int ES = BF16 ? 2 : 4;            // element size
-    constexpr int CE = 16 / ES;                 // elements per 16-B chunk
-    constexpr int SLAB_K = SLAB_BYTES / ES;     // K elements per slab
+    constexpr bool BF16 = MODE != 0;            // MFMA flavour
+    constexpr int ES = MODE == 1 ? 2 : 4;       // element size in memory
+    constexpr int CE = BF16 ? 8 : 4;            // K elements per 16-B LDS chunk
+    constexpr int SLAB_K = BF16 ? 64 : 32;      // K elements per slab
     __shared__ uint4 lds[2][2][TM * CHUNKS];    // [buffer][X|W][row*8 + swizzled chunk]
 
     // ---- XCD-aware tile id: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
@@ -135,8 +146,17 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
         const bool ok = k0 < a.K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            px[i] = ok ? *reinterpret_cast<const uint4*>(Xg + xoff[i] + kx * ES) : make_uint4(0, 0, 0, 0);
-            pw[i] = ok ? *reinterpret_cast<const uint4*>(Wg + woff[i] + k0 * ES) : make_uint4(0, 0, 0, 0);
+            if constexpr (MODE == 2) {
+                if (ok) {
+                    const float4* xp = reinterpret_cast<const float4*>(Xg + xoff[i] + kx * ES);
+                    const float4* wp = reinterpret_cast<const float4*>(Wg + woff[i] + k0 * ES);
+                    px[i] = pack_bf16x8(xp[0], xp[1]);
+                    pw[i] = pack_bf16x8(wp[0], wp[1]);
+                } else { px[i] = make_uint4(0, 0, 0, 0); pw[i] = px[i]; }
+            } else {
+                px[i] = ok ? *reinterpret_cast<const uint4*>(Xg + xoff[i] + kx * ES) : make_uint4(0, 0, 0, 0);
+                pw[i] = ok ? *reinterpret_cast<const uint4*>(Wg + woff[i] + k0 * ES) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
     auto write_lds = [&](int buf) {
@@ -280,6 +300,81 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_dma_kernel(const GemmArg
     gemm_epilogue(a, acc, m0, n0, wm, wn, fr, fq, cshift);
 }
 
+__global__ __launch_bounds__(THREADS, 2) void gemm_bf16_dma2_kernel(const GemmArgs a) {
+    constexpr int ES = 2, CE = 8, SLAB_K = 64;
+    __shared__ uint4 lds[2][2][TM * CHUNKS];    // [buffer][X|W][row*8 + position]
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    const long long m0 = (long long)tile_m * TM, n0 = (long long)tile_n * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const long long grp = blockIdx.y;
+    const char* Xg = a.X + grp * a.a_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const long long cshift = grp * a.c_gstride;
+
+    // staging: wave-instruction i of wave `wave` fills rows 8*wave + 32*i .. +7 (1 KiB, lane-linear)
+    const int pos = tid & 7, srow = tid >> 3;
+    const char* xsrc[4]; const char* wsrc[4];
+    int csrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = srow + 32 * i;
+        long long m = m0 + row; if (m > a.M - 1) m = a.M - 1;
+        long long n = n0 + row; if (n > a.N - 1) n = a.N - 1;
+        xsrc[i] = Xg + row_off(a.xmap, m) * ES;
+        wsrc[i] = Wg + n * a.ldw * ES;
+        csrc[i] = pos ^ (row & 7);              // source chunk of this lane
+    }
+    const int nslab = (int)(a.K / SLAB_K);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    auto stage = [&](int slab, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long k0 = (long long)slab * SLAB_K + csrc[i] * CE;
+            long long kx = k0;
+            if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
+            const int base = (wave * 8 + 32 * i) * CHUNKS;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx * ES), (lds_void*)&lds[buf][0][base], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + k0 * ES), (lds_void*)&lds[buf][1][base], 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    for (int slab = 0; slab < nslab; ++slab) {
+        const int cur = slab & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab `slab` has landed (this wave's pieces)
+        __syncthreads();                                       // ... everyone's pieces; buffer cur^1 is free again
+        if (slab + 1 < nslab) stage(slab + 1, cur ^ 1);        // next slab streams in under the MFMAs below
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 wf[4], xf[4];
+            const int chk = kb * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = wn * 64 + i * 16 + fr;
+                wf[i] = lds[cur][1][rw * CHUNKS + (chk ^ (rw & 7))];
+                const int rx = wm * 64 + i * 16 + fr;
+                xf[i] = lds[cur][0][rx * CHUNKS + (chk ^ (rx & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+    gemm_epilogue(a, acc, m0, n0, wm, wn, fr, fq, cshift);
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -288,11 +383,10 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     OCC_CHECK_ARG(d, "occ_gemm: null descriptor");
     OCC_CHECK_ARG(d->A && d->W && d->C, "occ_gemm: null operand");
     OCC_CHECK_ARG(d->M >= 1 && d->N >= 1 && d->K >= 1, "occ_gemm: bad shape M=%ld N=%ld K=%ld", (long)d->M, (long)d->N, (long)d->K);
-    OCC_CHECK_ARG(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_F32, "occ_gemm: ab_dtype must be bf16 or f32");
+    OCC_CHECK_ARG(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_F32 || d->ab_dtype == OCC_F32_AS_BF16, "occ_gemm: ab_dtype must be bf16, f32 or f32-as-bf16");
     OCC_CHECK_ARG(d->c_dtype == OCC_BF16 || d->c_dtype == OCC_F32, "occ_gemm: c_dtype must be bf16 or f32");
     OCC_CHECK_ARG(!d->R || d->r_dtype == OCC_BF16 || d->r_dtype == OCC_F32, "occ_gemm: r_dtype must be bf16 or f32");
-    const int es = d->ab_dtype == OCC_BF16 ? 2 : 4;
-    const int ce = 16 / es;
+    const int ce = d->ab_dtype == OCC_F32 ? 4 : 8;            // K granularity: one 16-byte LDS chunk
     OCC_CHECK_ARG(d->K % ce == 0 && d->N % 4 == 0, "occ_gemm: needs K %% %d == 0 and N %% 4 == 0 (K=%ld N=%ld)", ce, (long)d->K, (long)d->N);
     const long long nseg = d->a_nseg > 1 ? d->a_nseg : 1;
     const long long seg_len = nseg > 1 ? d->a_seg_len : d->K;
@@ -326,8 +420,11 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     static const int variant = getenv("OCC_GEMM_VARIANT") ? atoi(getenv("OCC_GEMM_VARIANT")) : 1;
     if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 1)
         hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
-    else if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<true>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
-    else hipLaunchKernelGGL(gemm_kernel<false>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 2)
+        hipLaunchKernelGGL(gemm_bf16_dma2_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    else if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<1>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    else if (d->ab_dtype == OCC_F32_AS_BF16) hipLaunchKernelGGL(gemm_kernel<2>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL(gemm_kernel<0>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     OCC_LAUNCH_CHECK("occ_gemm");
     return OCC_OK;
 }

@@ -17,7 +17,7 @@ import torch
 
 from .. import backend_ops as K
 from .. import ops
-from .._lib import ACT_NONE, ACT_SELU, ACT_TANH, OCC_F32, OccError, require_gpu
+from .._lib import ACT_NONE, ACT_SELU, ACT_TANH, OCC_F32, OCC_F32_AS_BF16, OccError, require_gpu
 from ..ops import rowmap
 from . import xlsr as xlsr_mod
 
@@ -91,8 +91,14 @@ _AW_ROW = {"att_weight": 0, "att_weight11": 0, "att_weight22": 1, "att_weight12"
 class AasistBackend:
     """Explicit forward/backward engine of the AASIST graph back-end (everything after the SSL features)."""
 
-    def __init__(self, params=None, device="cuda", seed=0):
+    def __init__(self, params=None, device="cuda", seed=0, compute="f32"):
+        """compute: "f32" = exact-f32 MFMA everywhere (parity path); "bf16" = Linear / Conv2d forward and input-gradient
+        GEMMs round their f32 operands to bf16 on the way into LDS (bf16 MFMA, f32 accumulate); weight gradients,
+        BatchNorm, softmax and every reduction stay f32."""
         require_gpu()
+        if compute not in ("f32", "bf16"):
+            raise OccError("compute must be 'f32' or 'bf16'")
+        self.compute = compute
         self.device = torch.device(device)
         self.table = backend_param_table()
         # ---- flat parameter / gradient storage (one Adam tensor, one all-reduce bucket) ----
@@ -216,6 +222,12 @@ class AasistBackend:
         return self._ws[key]
 
     # ---------------------------------------------------------------------------------- helpers --
+    def _gd(self, Kd, *strides):
+        """GEMM operand mode: bf16 compute needs K and every operand stride in multiples of 8 elements."""
+        if self.compute == "bf16" and Kd % 8 == 0 and all(int(v) % 8 == 0 for v in strides):
+            return OCC_F32_AS_BF16
+        return OCC_F32
+
     def _bn(self, name, x, x_map, rows, C, train, want_out=True):
         mean, rstd = (self._e(C), self._e(C)) if want_out else (None, None)
         K.bn_stats(x, x_map, rows, C, self.bn_ws, mean, rstd, self.buf[name + ".running_mean"], self.buf[name + ".running_var"],
@@ -224,8 +236,9 @@ class AasistBackend:
 
     def _lin(self, x, M, Kd, name, N, act=ACT_NONE, R=None, out=None, a_map=None, c_addr=None, c_map=None):
         out = out if out is not None else self._e(M, N)
-        ops.gemm_raw(M, N, Kd, x, a_map or rowmap(M, 0, Kd), self.p[name + ".weight"], Kd, c_addr if c_addr is not None else out,
-                     c_map or rowmap(M, 0, N), OCC_F32, OCC_F32, bias=self.p[name + ".bias"], act=act,
+        am = a_map or rowmap(M, 0, Kd)
+        ops.gemm_raw(M, N, Kd, x, am, self.p[name + ".weight"], Kd, c_addr if c_addr is not None else out,
+                     c_map or rowmap(M, 0, N), OCC_F32, self._gd(Kd, am.row_stride, am.batch_stride), bias=self.p[name + ".bias"], act=act,
                      R=R, r_map=None if R is None else rowmap(M, 0, N), r_dtype=OCC_F32)
         return out
 
@@ -237,7 +250,7 @@ class AasistBackend:
         wt = self._e(Kd, N)
         K.copy_strided(self.p[name + ".weight"], wt, 0, (1, 1, Kd, N), (0, 0, 1, Kd))
         out = dx if dx is not None else self._e(M, Kd)
-        ops.gemm_raw(M, Kd, N, dy, dy_map, wt, N, out, dx_map or rowmap(M, 0, Kd), OCC_F32, OCC_F32,
+        ops.gemm_raw(M, Kd, N, dy, dy_map, wt, N, out, dx_map or rowmap(M, 0, Kd), OCC_F32, self._gd(N, dy_map.row_stride, dy_map.batch_stride),
                      R=dx_R, r_map=dx_rmap, r_dtype=OCC_F32)
         return out
 
@@ -311,7 +324,7 @@ class AasistBackend:
                 self._bn(pre + ".bn1", X.data_ptr() + (Wp + 1) * ci * es, mp["x_in42"](ci), R, ci, True, want_out=False)
             R1 = B * 43 * W
             o1 = self._e(R1, co)
-            ops.gemm_raw(R1, co, 6 * ci, X, mp["x_win43"](ci), p[pre + ".conv1.weight"], 6 * ci, o1, rowmap(R1, 0, co), OCC_F32, OCC_F32,
+            ops.gemm_raw(R1, co, 6 * ci, X, mp["x_win43"](ci), p[pre + ".conv1.weight"], 6 * ci, o1, rowmap(R1, 0, co), OCC_F32, self._gd(3 * ci, ci),
                          bias=p[pre + ".conv1.bias"], a_seg=(2, 3 * ci, Wp * ci))
             c["o1_%d" % i] = o1
             c["bn2_%d" % i] = self._bn(pre + ".bn2", o1, rowmap(R1, 0, co), R1, co, train)
@@ -320,7 +333,7 @@ class AasistBackend:
             if ci0 != co:
                 ident = self._e(R, co)
                 ops.gemm_raw(R, co, 3 * ci, X.data_ptr() + Wp * ci * es, mp["x_in42"](ci), p[pre + ".conv_downsample.weight"], 3 * ci,
-                             ident, rowmap(R, 0, co), OCC_F32, OCC_F32, bias=p[pre + ".conv_downsample.bias"])
+                             ident, rowmap(R, 0, co), OCC_F32, self._gd(3 * ci, ci), bias=p[pre + ".conv_downsample.bias"])
                 r_addr, r_map = ident, rowmap(R, 0, co)
             else:
                 r_addr, r_map = X.data_ptr() + (Wp + 1) * ci * es, mp["x_in42"](ci)
@@ -328,7 +341,7 @@ class AasistBackend:
                 c_addr, c_map = ws["X%d" % (i + 1)].data_ptr() + (Wp + 1) * co * es, mp["x_in42"](co)
             else:
                 c_addr, c_map = enc, rowmap(R, 0, co)
-            ops.gemm_raw(R, co, 6 * co, Y, mp["y_win42"](co), p[pre + ".conv2.weight"], 6 * co, c_addr, c_map, OCC_F32, OCC_F32,
+            ops.gemm_raw(R, co, 6 * co, Y, mp["y_win42"](co), p[pre + ".conv2.weight"], 6 * co, c_addr, c_map, OCC_F32, self._gd(3 * co, co),
                          bias=p[pre + ".conv2.bias"], a_seg=(2, 3 * co, Wp * co), R=r_addr, r_map=r_map, r_dtype=OCC_F32)
         c["enc"] = enc
         c["bn.first_bn1"] = self._bn("first_bn1", enc, rowmap(R, 0, 64), R, 64, train)
@@ -347,6 +360,7 @@ class AasistBackend:
         eS, eT = self._e(B, 42, 64), self._e(B, W, 64)
         K.softmax_wsum_fwd(xa, wt, B * 42, 1, W * 64, 0, W, 64, 64, p["pos_S"], 42, eS)            # softmax over W per (b,h)
         K.softmax_wsum_fwd(xa, wt, B * W, W, 42 * W * 64, 64, 42, W * 64, 64, None, 1, eT)         # softmax over H per (b,w)
+        c["eS"], c["eT"] = eS, eT
         # ---- graph attention + pooling --------------------------------------------------------
         gS = self._gat_fwd("GAT_layer_S", eS, B, 42, c, train, masks)
         oS = self._pool_fwd("pool_S", gS, B, 42, 64, c, train, masks)
@@ -580,7 +594,7 @@ class AasistBackend:
             wd = self._e(co, 2, 3, co)
             K.copy_strided(p[pre + ".conv2.weight"], wd, 3 * co + 2 * co, (co, 2, 3, co), (1, -3 * co, -co, 6 * co))
             dY = self._e(R1, co)
-            ops.gemm_raw(R1, co, 6 * co, D, mp["d_win43"](co), wd, 6 * co, dY, rowmap(R1, 0, co), OCC_F32, OCC_F32, a_seg=(2, 3 * co, Wp * co))
+            ops.gemm_raw(R1, co, 6 * co, D, mp["d_win43"](co), wd, 6 * co, dY, rowmap(R1, 0, co), OCC_F32, self._gd(3 * co, co), a_seg=(2, 3 * co, Wp * co))
             # bn2 + selu backward -> grad wrt conv1 output into D1's interior
             K.bn_act_bwd(dY, rowmap(R1, 0, co), c["o1_%d" % i], rowmap(R1, 0, co), *c["bn2_%d" % i], p[pre + ".bn2.weight"], p[pre + ".bn2.bias"],
                          ACT_SELU, D1.data_ptr() + co * es, mp["y_in43"](co), g[pre + ".bn2.weight"], g[pre + ".bn2.bias"], self.bn_ws,
@@ -595,7 +609,7 @@ class AasistBackend:
                 wdd = self._e(ci, 1, 3, co)
                 K.copy_strided(p[pre + ".conv_downsample.weight"], wdd, 2 * ci, (ci, 1, 3, co), (1, 0, -ci, 3 * ci))
                 r_addr = self._e(R, ci)
-                ops.gemm_raw(R, ci, 3 * co, D.data_ptr() + Wp * co * es, mp["x_in42"](co), wdd, 3 * co, r_addr, rowmap(R, 0, ci), OCC_F32, OCC_F32)
+                ops.gemm_raw(R, ci, 3 * co, D.data_ptr() + Wp * co * es, mp["x_in42"](co), wdd, 3 * co, r_addr, rowmap(R, 0, ci), OCC_F32, self._gd(3 * co, co))
                 r_map = rowmap(R, 0, ci)
             else:
                 r_addr, r_map = d_in, mp["x_in42"](co)
@@ -607,7 +621,7 @@ class AasistBackend:
             else:
                 dx0 = self._e(R, ci)
                 c_addr, c_map = dx0, rowmap(R, 0, ci)
-            ops.gemm_raw(R, ci, 6 * co, D1, mp["y_win42"](co), wd1, 6 * co, c_addr, c_map, OCC_F32, OCC_F32, a_seg=(2, 3 * co, Wp * co),
+            ops.gemm_raw(R, ci, 6 * co, D1, mp["y_win42"](co), wd1, 6 * co, c_addr, c_map, OCC_F32, self._gd(3 * co, co), a_seg=(2, 3 * co, Wp * co),
                          R=r_addr, r_map=r_map, r_dtype=OCC_F32)
         # ---- stem: first_bn + selu, max-pool, LL ---------------------------------------------------
         dpool = self._e(R)
@@ -657,11 +671,14 @@ class AModel(torch.nn.Module):
     XLS-R variant, compute dtype and weights; ``backend_state_dict`` the AASIST weights; both fall back to the
     deterministic synthetic filler because no checkpoint exists offline (the reference hard-codes a path, :24)."""
 
-    def __init__(self, args=None, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, backend_state_dict=None, seed=0):
+    def __init__(self, args=None, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, backend_state_dict=None, seed=0,
+                 backend_compute=None):
         super().__init__()
         self.device = device
         self.ssl_model = SSLModel(device, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, seed=seed)
-        self.backend = AasistBackend(backend_state_dict, device=device, seed=seed)
+        if backend_compute is None:
+            backend_compute = "bf16" if ssl_dtype == torch.bfloat16 else "f32"
+        self.backend = AasistBackend(backend_state_dict, device=device, seed=seed, compute=backend_compute)
 
     def forward(self, x, masks=None):
         x = x.squeeze(-1) if x.dim() == 3 else x

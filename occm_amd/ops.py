@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, OCC_BF16, OCC_F32, OCC_F64,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, OCC_BF16, OCC_F32, OCC_F32_AS_BF16, OCC_F64,  # noqa: F401
                    GemmDesc, RowMap, check, dtype_code, lib, ptr, stream_ptr)
 
 
