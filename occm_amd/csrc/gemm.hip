@@ -229,34 +229,47 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
-__global__ __launch_bounds__(THREADS, 4) void gemm_bf16_dma_kernel(const GemmArgs a) {
+// TMT = 128: 4 waves (2x2), 32 KiB LDS, 4 workgroups per CU.  TMT = 256: 8 waves (4x2) on a 256x128 tile, 48 KiB LDS,
+// 2 workgroups per CU: the same 16 waves per CU but 25 % fewer L2->LDS bytes per FLOP (the 128x128 tile moves one byte
+// per 64 FLOP, which is about what a CU can pull from L2 at its MFMA rate).
+template <int TMT>
+__global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma_kernel(const GemmArgs a) {
     constexpr int ES = 2, CE = 8, SLAB_K = 64;
-    __shared__ uint4 lds[2][TM * CHUNKS];       // [X|W][row*8 + position]
+    constexpr int NT = 2 * TMT;                 // threads
+    constexpr int RPP = NT / 8;                 // rows staged per pass
+    constexpr int XP = TMT / RPP, WP = TN / RPP;
+    __shared__ uint4 lds[(TMT + TN) * CHUNKS];  // X rows then W rows: [row*8 + position]
+    uint4* ldsX = lds; uint4* ldsW = lds + TMT * CHUNKS;
     const int total = a.nbm * a.nbn;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
     const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
     const int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
-    const long long m0 = (long long)tile_m * TM, n0 = (long long)tile_n * TN;
+    const long long m0 = (long long)tile_m * TMT, n0 = (long long)tile_n * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = TMT == 128 ? (wave & 1) : (wave & 3), wn = TMT == 128 ? (wave >> 1) : (wave >> 2);
     const long long grp = blockIdx.y;
     const char* Xg = a.X + grp * a.a_gstride * ES;
     const char* Wg = a.W + grp * a.w_gstride * ES;
     const long long cshift = grp * a.c_gstride;
 
-    // staging: wave-instruction i of wave `wave` fills rows 8*wave + 32*i .. +7 (1 KiB, lane-linear)
+    // staging: one wave-instruction fills 8 rows (1 KiB, lane-linear); pass i covers rows i*RPP .. i*RPP + RPP-1
     const int pos = tid & 7, srow = tid >> 3;
-    const char* xsrc[4]; const char* wsrc[4];
-    int csrc[4];
+    const char* xsrc[XP]; const char* wsrc[WP];
+    int xc[XP], wc[WP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = srow + 32 * i;
+    for (int i = 0; i < XP; ++i) {
+        const int row = srow + RPP * i;
         long long m = m0 + row; if (m > a.M - 1) m = a.M - 1;
-        long long n = n0 + row; if (n > a.N - 1) n = a.N - 1;
         xsrc[i] = Xg + row_off(a.xmap, m) * ES;
+        xc[i] = pos ^ (row & 7);
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int row = srow + RPP * i;
+        long long n = n0 + row; if (n > a.N - 1) n = a.N - 1;
         wsrc[i] = Wg + n * a.ldw * ES;
-        csrc[i] = pos ^ (row & 7);              // source chunk of this lane
+        wc[i] = pos ^ (row & 7);
     }
     const int nslab = (int)(a.K / SLAB_K);
     f32x4 acc[4][4];
@@ -267,13 +280,16 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_dma_kernel(const GemmArg
     const int fr = lane & 15, fq = lane >> 4;
     for (int slab = 0; slab < nslab; ++slab) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long k0 = (long long)slab * SLAB_K + csrc[i] * CE;
+        for (int i = 0; i < XP; ++i) {
+            const long long k0 = (long long)slab * SLAB_K + xc[i] * CE;
             long long kx = k0;
             if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
-            const int base = (wave * 8 + 32 * i) * CHUNKS;          // wave-uniform LDS row block
-            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx * ES), (lds_void*)&lds[0][base], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + k0 * ES), (lds_void*)&lds[1][base], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx * ES), (lds_void*)&ldsX[(wave * 8 + RPP * i) * CHUNKS], 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            const long long k0 = (long long)slab * SLAB_K + wc[i] * CE;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + k0 * ES), (lds_void*)&ldsW[(wave * 8 + RPP * i) * CHUNKS], 16, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -284,9 +300,9 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_dma_kernel(const GemmArg
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rw = wn * 64 + i * 16 + fr;
-                wf[i] = lds[1][rw * CHUNKS + (chk ^ (rw & 7))];
+                wf[i] = ldsW[rw * CHUNKS + (chk ^ (rw & 7))];
                 const int rx = wm * 64 + i * 16 + fr;
-                xf[i] = lds[0][rx * CHUNKS + (chk ^ (rx & 7))];
+                xf[i] = ldsX[rx * CHUNKS + (chk ^ (rx & 7))];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -418,8 +434,13 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     OCC_CHECK_ARG(total < (1ll << 30), "occ_gemm: too many tiles");
     hipStream_t s = (hipStream_t)stream;
     static const int variant = getenv("OCC_GEMM_VARIANT") ? atoi(getenv("OCC_GEMM_VARIANT")) : 1;
-    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 1)
-        hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    const long long nbm256 = occ_cdiv(d->M, 256);
+    const bool big = nbm256 * a.nbn >= 512;          // enough 256x128 tiles to fill 256 CUs x 2
+    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 3 || (variant == 1 && big))) {
+        a.nbm = (int)nbm256;
+        hipLaunchKernelGGL(gemm_bf16_dma_kernel<256>, dim3((unsigned)(nbm256 * a.nbn), (unsigned)ng), dim3(512), 0, s, a);
+    } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 1 || variant == 4))
+        hipLaunchKernelGGL(gemm_bf16_dma_kernel<128>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 2)
         hipLaunchKernelGGL(gemm_bf16_dma2_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<1>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
