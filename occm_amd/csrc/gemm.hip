@@ -435,7 +435,9 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static const int variant = getenv("OCC_GEMM_VARIANT") ? atoi(getenv("OCC_GEMM_VARIANT")) : 1;
     const long long nbm256 = occ_cdiv(d->M, 256);
-    const bool big = nbm256 * a.nbn >= 512;          // enough 256x128 tiles to fill 256 CUs x 2
+    // 256x128 tiles only pay on large square problems (4096^3: 999 vs 865 TFLOP/s); on the front-end shapes (M = 6368, or N = 512)
+    // the 128x128 tile's finer granularity wins by 3-15 % (scripts/bench_gemm.py), so it stays the default there.
+    const bool big = d->M >= 4096 && d->N >= 4096 && d->M % 256 == 0;
     if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 3 || (variant == 1 && big))) {
         a.nbm = (int)nbm256;
         hipLaunchKernelGGL(gemm_bf16_dma_kernel<256>, dim3((unsigned)(nbm256 * a.nbn), (unsigned)ng), dim3(512), 0, s, a);

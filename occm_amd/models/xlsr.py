@@ -118,8 +118,8 @@ class XlsrFrontend:
         self.w = w
 
     # -- activation workspace, cached per (B, L) -------------------------------------------------
-    def _workspace(self, B, L):
-        key = (B, L)
+    def _workspace(self, B, L, slot=0):
+        key = (B, L, slot)
         if key not in self._ws:
             dev, dt, cfg = self.device, self.dtype, self.cfg
             Ts, Lc = [], L
@@ -143,14 +143,16 @@ class XlsrFrontend:
             self._ws[key] = ws
         return self._ws[key]
 
-    def forward(self, wav, out_dtype=None, taps=None):
-        """wav f32 [B,L] on the GPU -> [B,T,dim] (dtype = out_dtype or the compute dtype)."""
+    def forward(self, wav, out_dtype=None, taps=None, slot=0, out=None):
+        """wav f32 [B,L] on the GPU -> [B,T,dim] (dtype = out_dtype or the compute dtype).  ``slot`` selects an independent
+        activation workspace so two half-batches can run concurrently on two streams; ``out`` is an optional destination."""
         cfg, w, dt = self.cfg, self.w, self.dtype
+        dst = out
         if wav.dim() == 3:
             wav = wav[:, :, 0]                                   # sslassist.py:42-43
         wav = wav.to(self.device, torch.float32).contiguous()
         B, L = wav.shape
-        ws = self._workspace(B, L)
+        ws = self._workspace(B, L, slot)
         Ts, T, M = ws["Ts"], ws["T"], ws["M"]
         code = dtype_code(ws["h"])
         D = cfg.dim
@@ -202,9 +204,10 @@ class XlsrFrontend:
                          bias=w["l%d.fc2.b" % i], R=x, r_map=xmap, r_dtype=OCC_F32)
             if taps is not None:
                 taps["layer%d" % i] = x.view(B, T, D).clone()
-        out = torch.empty(B, T, D, device=self.device, dtype=out_dtype or dt)
-        ops.layernorm(x, w["enc_ln.g"], w["enc_ln.b"], out=out.view(M, D))
-        return out
+        if dst is None:
+            dst = torch.empty(B, T, D, device=self.device, dtype=out_dtype or dt)
+        ops.layernorm(x, w["enc_ln.g"], w["enc_ln.b"], out=dst.view(M, D))
+        return dst
 
 
 class SSLModel(torch.nn.Module):
