@@ -44,15 +44,54 @@ def gemm_flops_per_utt(cfg, L):
     return fe + proj + pos + lin
 
 
+def usable_cores():
+    """Cores this job may really use: the cgroup CPU quota when there is one (a 1-GPU box exposes all host CPUs but grants a
+    share), else the affinity mask; never more than 64 threads (the oracle's small ops stop scaling long before)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    n = min(n, int(os.environ.get("OCC_CPU_THREADS", "64")))
+    return max(1, n)
+
+
+def gemm_bytes_per_step(cfg, L, B):
+    """Algorithmic HBM bytes of the bf16 GEMM launches of one step: each launch reads A and W once and writes C once."""
+    Ts, Lc = [], L
+    for k, s in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
+        Lc = (Lc - k) // s + 1
+        Ts.append(Lc)
+    T, d, f, n = Ts[-1], cfg.dim, cfg.ffn, cfg.layers
+    M = B * T
+    tot = 0
+    for i in range(1, 7):
+        k = 3 if i < 5 else 2
+        tot += B * Ts[i - 1] * 512 * 2 + 512 * k * 512 * 2 + B * Ts[i] * 512 * 2
+    tot += M * 512 * 2 + d * 512 * 2 + M * d * 2                                   # post_extract_proj
+    tot += B * (T + cfg.pos_k) * d * 2 + d * (d // cfg.pos_groups) * cfg.pos_k * 2 + M * d * 4 + M * d * 2   # pos conv (+residual)
+    per_layer = (M * d * 2 + 3 * d * d * 2 + M * 3 * d * 2) + (M * d * 2 + d * d * 2 + 2 * M * d * 4) \
+        + (M * d * 2 + f * d * 2 + M * f * 2) + (M * f * 2 + d * f * 2 + 2 * M * d * 4)
+    return tot + n * per_layer
+
+
 def cpu_baseline(budget_s=25.0):
     """The torch-CPU oracle (kind "port": the reference's fairseq front-end cannot run) on a bounded sample of the same
     workload: frozen XLS-R-300M forward + AASIST fwd/bwd + Adam, bs=2, as many steps as fit the budget (>= 1)."""
     from oracle import aasist_ref, losses_ref, xlsr_ref
     from oracle.fill import fill_like
-    try:
-        cores = len(os.sched_getaffinity(0))         # the cores this job may actually use (a 1-GPU box exposes a share)
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = xlsr_ref.XlsrConfig.xlsr_300m()
     px = fill_like(xlsr_ref.param_shapes(cfg), seed=0)
@@ -162,10 +201,17 @@ def main():
         n_launch = sum(1 for kind, _, _ in recs if kind == "gemm_bf16") // 3
         fl = gemm_flops_per_utt(cfg, L_SAMPLES) * BS
         ach = fl / (t_ms * 1e-3) / 1e12
-        roof = {"kernel": "gemm_kernel<bf16> (all front-end Linear/Conv1d launches of one step)", "bound": "mfma",
+        traffic, tnote = None, None
+        try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
+            traffic = pm["kernels"]["gemm_bf16_dma_kernel<128>"]["hbm_bytes_per_launch_corrected"]
+            tnote = "profiles/r01_pmc_hbm.json (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE)"
+        except (OSError, KeyError, ValueError):
+            pass
+        roof = {"kernel": "gemm_bf16_dma_kernel (all front-end Linear/Conv1d launches of one step)", "bound": "mfma",
                 "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                "traffic": None, "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / max(n_launch, 1), 2),
-                "flops_per_step": fl}
+                "traffic": traffic, "traffic_source": tnote, "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(cfg, L_SAMPLES, BS) / max(n_launch, 1)),
+                "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / max(n_launch, 1), 2), "flops_per_step": fl}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -175,7 +221,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "XLSR-300M frozen frontend + AASIST backend, bs=32 per GPU, 64000-sample utterances (BASELINE configs[1])",
                           "global_batch": BS * world, "samples_per_utt": L_SAMPLES, "parallelism": "dp%d" % world,
-                          "frontend": "bf16 MFMA, f32 accumulate, HIP-graph replay", "backend": "f32 MFMA fwd+bwd, dropout on, Adam lr=1e-5",
+                          "frontend": "bf16 MFMA, f32 accumulate, HIP-graph replay", "backend": "fwd+bwd, f32 storage, bf16-MFMA GEMMs (f32 accumulate), f32 wgrad, dropout on, Adam lr=1e-5",
                           "loss": "0.0*compactness + 1.0*descriptiveness (oc_training.py:380-381)", "final_loss_d": round(loss_d, 5)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))

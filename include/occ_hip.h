@@ -22,8 +22,10 @@ extern "C" {
 #endif
 
 enum occ_status { OCC_OK = 0, OCC_EINVAL = -1, OCC_ELAUNCH = -2, OCC_EUNSUPPORTED = -3 };
-enum occ_dtype { OCC_F32 = 0, OCC_BF16 = 1, OCC_F64 = 2, OCC_F32_AS_BF16 = 3 /* occ_gemm ab_dtype only: f32 operands in memory, rounded to bf16 on the way into LDS, bf16 MFMA */ };
-enum occ_act { OCC_ACT_NONE = 0, OCC_ACT_GELU = 1, OCC_ACT_SELU = 2, OCC_ACT_RELU = 3, OCC_ACT_TANH = 4 };
+enum occ_dtype { OCC_F32 = 0, OCC_BF16 = 1, OCC_F64 = 2, OCC_F32_AS_BF16 = 3 /* occ_gemm ab_dtype only: f32 operands in memory, rounded to bf16 on the way into LDS, bf16 MFMA */,
+                 OCC_AF32_WBF16 = 4 /* occ_gemm ab_dtype only: A f32 in memory (rounded to bf16 while staged), W bf16 */ };
+enum occ_act { OCC_ACT_NONE = 0, OCC_ACT_GELU = 1, OCC_ACT_SELU = 2, OCC_ACT_RELU = 3, OCC_ACT_TANH = 4,
+               OCC_ACT_GELU_GRAD = 5 /* occ_gemm epilogue: (acc+bias) * gelu'(aux) */ };
 
 const char* occ_last_error(void);
 int occ_version(void);
@@ -106,6 +108,9 @@ typedef struct occ_gemm_desc {
     /* grouped problems (grouped Conv1d): group g uses A + g*a_group_stride, W + g*w_group_stride and
      * output/bias/residual columns shifted by g*c_group_stride; n_groups <= 1 means a single problem. */
     int64_t n_groups, a_group_stride, w_group_stride, c_group_stride;
+    /* optional bf16 side tensor addressed like C (same row map): with act = OCC_ACT_GELU the pre-activation (acc+bias) is
+     * stored to it (saved for backward); with act = OCC_ACT_GELU_GRAD it is read (the saved pre-activation).  NULL = unused. */
+    void* aux;
 } occ_gemm_desc;
 /* C = act(alpha * A.W^T + bias) + R.  Replaces every nn.Linear / Conv1d of the path
  * (fairseq wav2vec2 layers reached from sslassist.py:48; AModel.LL sslassist.py:509).             */

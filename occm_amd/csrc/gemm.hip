@@ -32,6 +32,7 @@ struct GemmArgs {
     const char* R; RowMapI rmap; int r_dtype;
     char* C; RowMapI cmap; int c_dtype;
     int act; float alpha;
+    unsigned short* aux;
     int nbm, nbn;
     long long a_gstride, w_gstride, c_gstride;
 };
@@ -66,7 +67,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
                 const float4 bv = *reinterpret_cast<const float4*>(a.bias + cshift + n);
                 v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
             }
-            if (a.act != OCC_ACT_NONE) {
+            if (a.aux && a.act == OCC_ACT_GELU) {                       // keep the pre-activation for backward
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2*>(a.aux + coff + n) = o;
+            }
+            if (a.act == OCC_ACT_GELU_GRAD) {
+                const uint2 u = *reinterpret_cast<const uint2*>(a.aux + coff + n);
+                v[0] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x & 0xffff))); v[1] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x >> 16)));
+                v[2] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y & 0xffff))); v[3] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y >> 16)));
+            } else if (a.act != OCC_ACT_NONE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_rt(a.act, v[e]);
             }
@@ -105,7 +116,8 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float4 lo, const float4 hi) {
 template <int MODE>
 __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
     constexpr bool BF16 = MODE != 0;            // MFMA flavour
-    constexpr int ES = MODE == 1 ? 2 : 4;       // element size in memory
+    constexpr int ES = MODE == 1 ? 2 : 4;       // element size of X in memory (MODE 3: X f32, W bf16)
+    constexpr int WES = (MODE == 1 || MODE == 3) ? 2 : 4;
     constexpr int CE = BF16 ? 8 : 4;            // K elements per 16-B LDS chunk
     constexpr int SLAB_K = BF16 ? 64 : 32;      // K elements per slab
     __shared__ uint4 lds[2][2][TM * CHUNKS];    // [buffer][X|W][row*8 + swizzled chunk]
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
     const int wm = wave & 1, wn = wave >> 1;
     const long long grp = blockIdx.y;
     const char* Xg = a.X + grp * a.a_gstride * ES;
-    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * WES;
     const long long cshift = grp * a.c_gstride;      // column shift of C / R / bias for this group
 
     // ---- staging assignment: this thread copies chunk `ch` of rows (tid>>3) + 32*i
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
         long long m = m0 + srow + 32 * i; if (m > a.M - 1) m = a.M - 1;
         long long n = n0 + srow + 32 * i; if (n > a.N - 1) n = a.N - 1;
         xoff[i] = row_off(a.xmap, m) * ES;
-        woff[i] = n * a.ldw * ES;
+        woff[i] = n * a.ldw * WES;
     }
     const int nslab = (int)((a.K + SLAB_K - 1) / SLAB_K);
 
@@ -146,12 +158,16 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
         const bool ok = k0 < a.K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if constexpr (MODE == 2) {
+            if constexpr (MODE == 2 || MODE == 3) {
                 if (ok) {
                     const float4* xp = reinterpret_cast<const float4*>(Xg + xoff[i] + kx * ES);
-                    const float4* wp = reinterpret_cast<const float4*>(Wg + woff[i] + k0 * ES);
                     px[i] = pack_bf16x8(xp[0], xp[1]);
-                    pw[i] = pack_bf16x8(wp[0], wp[1]);
+                    if constexpr (MODE == 2) {
+                        const float4* wp = reinterpret_cast<const float4*>(Wg + woff[i] + k0 * WES);
+                        pw[i] = pack_bf16x8(wp[0], wp[1]);
+                    } else {
+                        pw[i] = *reinterpret_cast<const uint4*>(Wg + woff[i] + k0 * WES);
+                    }
                 } else { px[i] = make_uint4(0, 0, 0, 0); pw[i] = px[i]; }
             } else {
                 px[i] = ok ? *reinterpret_cast<const uint4*>(Xg + xoff[i] + kx * ES) : make_uint4(0, 0, 0, 0);
@@ -399,7 +415,9 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     OCC_CHECK_ARG(d, "occ_gemm: null descriptor");
     OCC_CHECK_ARG(d->A && d->W && d->C, "occ_gemm: null operand");
     OCC_CHECK_ARG(d->M >= 1 && d->N >= 1 && d->K >= 1, "occ_gemm: bad shape M=%ld N=%ld K=%ld", (long)d->M, (long)d->N, (long)d->K);
-    OCC_CHECK_ARG(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_F32 || d->ab_dtype == OCC_F32_AS_BF16, "occ_gemm: ab_dtype must be bf16, f32 or f32-as-bf16");
+    OCC_CHECK_ARG(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_F32 || d->ab_dtype == OCC_F32_AS_BF16 || d->ab_dtype == OCC_AF32_WBF16,
+                  "occ_gemm: ab_dtype must be bf16, f32, f32-as-bf16 or af32-wbf16");
+    OCC_CHECK_ARG(!(d->act == OCC_ACT_GELU_GRAD && !d->aux), "occ_gemm: OCC_ACT_GELU_GRAD needs aux");
     OCC_CHECK_ARG(d->c_dtype == OCC_BF16 || d->c_dtype == OCC_F32, "occ_gemm: c_dtype must be bf16 or f32");
     OCC_CHECK_ARG(!d->R || d->r_dtype == OCC_BF16 || d->r_dtype == OCC_F32, "occ_gemm: r_dtype must be bf16 or f32");
     const int ce = d->ab_dtype == OCC_F32 ? 4 : 8;            // K granularity: one 16-byte LDS chunk
@@ -425,7 +443,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     a.bias = (const float*)d->bias;
     a.R = (const char*)d->R; a.rmap = to_rowmap(d->r_map); a.r_dtype = d->r_dtype;
     a.C = (char*)d->C; a.cmap = to_rowmap(d->c_map); a.c_dtype = d->c_dtype;
-    a.act = d->act; a.alpha = d->alpha;
+    a.act = d->act; a.alpha = d->alpha; a.aux = (unsigned short*)d->aux;
     a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
     const long long ng = d->n_groups > 1 ? d->n_groups : 1;
     a.a_gstride = ng > 1 ? d->a_group_stride : 0; a.w_gstride = ng > 1 ? d->w_group_stride : 0; a.c_gstride = ng > 1 ? d->c_group_stride : 0;
@@ -447,6 +465,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         hipLaunchKernelGGL(gemm_bf16_dma2_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<1>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else if (d->ab_dtype == OCC_F32_AS_BF16) hipLaunchKernelGGL(gemm_kernel<2>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    else if (d->ab_dtype == OCC_AF32_WBF16) hipLaunchKernelGGL(gemm_kernel<3>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else hipLaunchKernelGGL(gemm_kernel<0>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     OCC_LAUNCH_CHECK("occ_gemm");
     return OCC_OK;

@@ -77,6 +77,12 @@ __device__ __forceinline__ float fast_erf(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
+// d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x * exp(-x^2/2) / sqrt(2 pi)
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.5f * x * x * 1.44269504088896340736f);
+    return fmaf(x, pdf, cdf);
+}
 __device__ __forceinline__ float selu_f(float x) {
     const float a = 1.6732632423543772848170429916717f, s = 1.0507009873554804934193349852946f;
     return x > 0.f ? s * x : s * a * (expf(x) - 1.0f);

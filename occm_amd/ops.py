@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, OCC_BF16, OCC_F32, OCC_F32_AS_BF16, OCC_F64,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_GELU_GRAD, ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, OCC_AF32_WBF16, OCC_BF16, OCC_F32, OCC_F32_AS_BF16, OCC_F64,  # noqa: F401
                    GemmDesc, RowMap, check, dtype_code, lib, ptr, stream_ptr)
 
 
@@ -28,7 +28,7 @@ def rowmap(rows_per_batch, batch_stride, row_stride, rows_per_line=0, line_strid
 
 
 def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, act=ACT_NONE, alpha=1.0,
-             R=None, r_map=None, r_dtype=OCC_F32, a_seg=None, groups=None):
+             R=None, r_map=None, r_dtype=OCC_F32, a_seg=None, groups=None, aux=None):
     """Direct descriptor-level call.  A/W/C/R/bias are ints (device addresses) or tensors."""
     d = GemmDesc()
     d.M, d.N, d.K = int(M), int(N), int(K)
@@ -53,12 +53,14 @@ def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, 
     d.alpha = float(alpha)
     if groups is not None:
         d.n_groups, d.a_group_stride, d.w_group_stride, d.c_group_stride = [int(v) for v in groups]
+    if aux is not None:
+        d.aux = aux if isinstance(aux, int) else aux.data_ptr()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib().occ_gemm(ctypes.byref(d), stream_ptr()), "occ_gemm")
         e1.record()
-        PROFILE.append(("gemm_bf16" if ab_dtype == OCC_BF16 else "gemm_f32", e0, e1))
+        PROFILE.append(("gemm_bf16" if ab_dtype in (OCC_BF16, OCC_AF32_WBF16) else "gemm_f32", e0, e1))
         return
     check(lib().occ_gemm(ctypes.byref(d), stream_ptr()), "occ_gemm")
 
