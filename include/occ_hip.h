@@ -130,7 +130,7 @@ typedef struct occ_gemm_tn_desc {
 } occ_gemm_tn_desc;
 int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream);
 /* out[n] += alpha * sum_m A[m,n] (bias gradients).                                                   */
-int occ_colsum(const float* A, const occ_rowmap* a_map, int64_t M, int64_t N, float* out, float alpha, void* stream);
+int occ_colsum(const void* A, int a_dtype, const occ_rowmap* a_map, int64_t M, int64_t N, float* out, float alpha, void* stream);   /* A f32 or bf16 */
 
 /* --------------------------------------------- AASIST back-end (models/sslassist.py:58-597), f32 ---- */
 int occ_fill_f32(float* p, float v, int64_t n, void* stream);
@@ -240,8 +240,21 @@ int occ_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const
                       int64_t C, int64_t k, int64_t stride, float eps, void* stream);
 /* Multi-head self-attention core softmax(Q.K^T).V for short sequences (T <= 1024), head_dim 64/80.
  * qkv: [B*T, 3*D] rows (q | k | v); scores are scale * q.k (fairseq scales q by hd^-0.5); out: [B*T, D].  */
+/* lse (optional, f32 [B*H, T], bf16 / head_dim 64 / T <= 256 path only): log2-sum-exp2 of the scaled scores, kept for backward. */
 int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd,
-                  int64_t ld_qkv, int64_t ld_out, float scale, void* stream);
+                  int64_t ld_qkv, int64_t ld_out, float scale, float* lse, void* stream);
+/* ---- backward of the transformer encoder (fine-tuning; autograd of fairseq's pre-LN TransformerSentenceEncoderLayer) ---- */
+/* dst[c, r] = bf16(src[r, c]) (src f32 or bf16 [rows, ld_src], dst bf16 [cols, ld_dst >= rows]): K-contiguous operands for the
+ * weight-gradient GEMMs dW = dY^T X, which then run on the same bf16 MFMA GEMM as the forward.                */
+int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
+                       void* stream);
+/* dx = LayerNorm'(x)^T dy (+ dres, the residual-branch gradient; dx may alias dres); dgamma += sum dy*xhat; dbeta += sum dy. */
+int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, float* dgamma,
+                      float* dbeta, int64_t rows, int64_t C, float eps, void* stream);
+/* dq|dk|dv (bf16 [B*T, 3D], same layout as qkv) of softmax(scale q.k^T) v given o (forward output), dout and the forward's lse.
+ * head_dim 64, T <= 256.                                                                                     */
+int occ_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H,
+                      int64_t hd, int64_t ld_qkv, int64_t ld_o, float scale, void* stream);
 
 #ifdef __cplusplus
 }

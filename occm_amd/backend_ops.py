@@ -44,8 +44,11 @@ def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsu
     check(lib().occ_gemm_tn(ctypes.byref(d), stream_ptr()), "occ_gemm_tn")
 
 
-def colsum(A, a_map, M, N, out, alpha=1.0):
-    check(lib().occ_colsum(_a(A), ctypes.byref(a_map), int(M), int(N), _a(out), float(alpha), stream_ptr()), "occ_colsum")
+def colsum(A, a_map, M, N, out, alpha=1.0, a_dtype=0):
+    """a_dtype: 0 = f32 (default), 1 = bf16; pass a tensor for A to have it inferred."""
+    if hasattr(A, "dtype"):
+        a_dtype = 1 if A.dtype == torch.bfloat16 else 0
+    check(lib().occ_colsum(_a(A), int(a_dtype), ctypes.byref(a_map), int(M), int(N), _a(out), float(alpha), stream_ptr()), "occ_colsum")
 
 
 def fill(t, v=0.0):

@@ -233,7 +233,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
 
 template <int NP>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
-                                                            int Tn, int H, long long ld_qkv, long long ld_out, float scale) {
+                                                            int Tn, int H, long long ld_qkv, long long ld_out, float scale, float* __restrict__ lse) {
     constexpr int NK = NP * 32;            // padded key count
     constexpr int VS = NK + 4;             // V^T row stride (elements): 8-byte aligned, bank-spreading
     __shared__ uint4 Ks[NK * 8];
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
+    if (lse && g == 0 && qrow < Tn) lse[(size_t)bh * Tn + qrow] = mx + __builtin_amdgcn_logf(sum);   // log2-sum-exp2 of the scaled scores (for backward)
 
     af32x4 oacc[4];
 #pragma unroll
@@ -339,9 +340,9 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
 }
 
 template <int NP>
-void launch_attention_mfma(const void* qkv, void* out, int B, int T, int H, long long ld_qkv, long long ld_out, float scale, hipStream_t s) {
+void launch_attention_mfma(const void* qkv, void* out, int B, int T, int H, long long ld_qkv, long long ld_out, float scale, float* lse, hipStream_t s) {
     const dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64)), block(256);
-    hipLaunchKernelGGL(attention_mfma_kernel<NP>, grid, block, 0, s, (const unsigned short*)qkv, (unsigned short*)out, T, H, ld_qkv, ld_out, scale);
+    hipLaunchKernelGGL(attention_mfma_kernel<NP>, grid, block, 0, s, (const unsigned short*)qkv, (unsigned short*)out, T, H, ld_qkv, ld_out, scale, lse);
 }
 
 }  // namespace
@@ -382,7 +383,7 @@ int occ_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const
 }
 
 int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd, int64_t ld_qkv, int64_t ld_out,
-                  float scale, void* stream) {
+                  float scale, float* lse, void* stream) {
     OCC_CHECK_ARG(qkv && out, "occ_attention: null pointer");
     OCC_CHECK_ARG(B >= 1 && T >= 1 && H >= 1 && hd >= 8 && hd <= 128, "occ_attention: bad shape");
     OCC_CHECK_ARG(T <= 1024, "occ_attention: T=%ld exceeds the short-sequence limit 1024", (long)T);
@@ -390,14 +391,15 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
     hipStream_t s = (hipStream_t)stream;
     if (dtype == OCC_BF16 && hd == 64 && T <= 256 && ld_qkv % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) {
         const int np = (int)((T + 31) / 32);
-        if (np <= 1) launch_attention_mfma<1>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, s);
-        else if (np <= 2) launch_attention_mfma<2>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, s);
-        else if (np <= 4) launch_attention_mfma<4>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, s);
-        else if (np <= 7) launch_attention_mfma<7>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, s);
-        else launch_attention_mfma<8>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, s);
+        if (np <= 1) launch_attention_mfma<1>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
+        else if (np <= 2) launch_attention_mfma<2>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
+        else if (np <= 4) launch_attention_mfma<4>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
+        else if (np <= 7) launch_attention_mfma<7>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
+        else launch_attention_mfma<8>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
         OCC_LAUNCH_CHECK("occ_attention(mfma)");
         return OCC_OK;
     }
+    OCC_CHECK_ARG(!lse, "occ_attention: the log-sum-exp output needs the bf16 / head_dim 64 / T <= 256 MFMA path");
     const size_t shm = ((size_t)2 * T * (hd + 1) + 4 * T + 4 * hd) * sizeof(float);
     OCC_CHECK_ARG(shm <= 160 * 1024, "occ_attention: T=%ld hd=%ld needs %zu B of LDS (> 160 KiB)", (long)T, (long)hd, shm);
     const int qsplit = 4;

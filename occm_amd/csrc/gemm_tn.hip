@@ -109,7 +109,8 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
 }
 
 // out[n] += alpha * sum_m A[m, n]
-__global__ __launch_bounds__(THREADS) void colsum_kernel(const float* __restrict__ A, RowMapI amap, long long M, long long N,
+template <typename T>
+__global__ __launch_bounds__(THREADS) void colsum_kernel(const T* __restrict__ A, RowMapI amap, long long M, long long N,
                                                          long long rows_per_split, float* __restrict__ out, float alpha) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(THREADS) void colsum_kernel(const float* __restrict
     const long long m_end = m_begin + rows_per_split < M ? m_begin + rows_per_split : M;
     float s = 0.f;
     if (n < N)
-        for (long long m = m_begin + wave; m < m_end; m += 4) s += A[row_off(amap, m) + n];
+        for (long long m = m_begin + wave; m < m_end; m += 4) s += occ_load_f32(A + row_off(amap, m) + n);
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && n < N) atomicAdd(out + n, (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * alpha);
@@ -159,14 +160,19 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
     return OCC_OK;
 }
 
-int occ_colsum(const float* A, const occ_rowmap* a_map, int64_t M, int64_t N, float* out, float alpha, void* stream) {
+int occ_colsum(const void* A, int a_dtype, const occ_rowmap* a_map, int64_t M, int64_t N, float* out, float alpha, void* stream) {
     OCC_CHECK_ARG(A && a_map && out && M >= 1 && N >= 1 && a_map->rows_per_batch >= 1, "occ_colsum: bad argument");
+    OCC_CHECK_ARG(a_dtype == OCC_F32 || a_dtype == OCC_BF16, "occ_colsum: A must be f32 or bf16");
     long long split = occ_cdiv(M, 512);
     if (split > 256) split = 256;
     const long long rps = occ_cdiv(M, split);
     split = occ_cdiv(M, rps);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)occ_cdiv(N, 64), (unsigned)split), dim3(THREADS), 0, (hipStream_t)stream, A,
-                       to_rowmap(*a_map), (long long)M, (long long)N, rps, out, alpha);
+    if (a_dtype == OCC_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)occ_cdiv(N, 64), (unsigned)split), dim3(THREADS), 0, (hipStream_t)stream, (const float*)A,
+                           to_rowmap(*a_map), (long long)M, (long long)N, rps, out, alpha);
+    else
+        hipLaunchKernelGGL(colsum_kernel<unsigned short>, dim3((unsigned)occ_cdiv(N, 64), (unsigned)split), dim3(THREADS), 0, (hipStream_t)stream,
+                           (const unsigned short*)A, to_rowmap(*a_map), (long long)M, (long long)N, rps, out, alpha);
     OCC_LAUNCH_CHECK("occ_colsum");
     return OCC_OK;
 }

@@ -15,7 +15,7 @@ the grouped positional conv reads as 128 K-segments.
 import torch
 
 from .. import ops
-from .._lib import ACT_GELU, ACT_NONE, OCC_F32, OccError, dtype_code, require_gpu
+from .._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, OCC_AF32_WBF16, OCC_BF16 as OCC_BF16_CODE, OCC_F32, OccError, dtype_code, require_gpu
 from ..ops import rowmap
 
 CONV_LAYERS = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2     # fairseq conv_feature_layers of XLS-R
@@ -264,3 +264,226 @@ def synthetic_params(cfg, seed=0):
             t = r / math.sqrt(max(fan_in, 1))
         out[name] = t
     return out
+
+
+class XlsrFineTuner(XlsrFrontend):
+    """Front-end with a TRAINABLE transformer encoder (24 pre-LN layers + final LayerNorm); the conv feature extractor,
+    projection and positional conv stay frozen this round (fairseq's ``feature_grad_mult = 0`` style fine-tuning).
+
+    f32 master weights / gradients live in two flat buffers (one Adam tensor, one all-reduce stream); every step the GEMM
+    operands are refreshed from them: W as bf16 (forward) and W^T as bf16 (input gradients).  Weight gradients are
+    dW = dY^T.X computed by the same bf16 MFMA GEMM on transposed bf16 copies ([N, Mp] and [K, Mp], Mp = M rounded up to 64).
+    Saved for backward per layer: the f32 residual stream before each LayerNorm, the LayerNorm outputs, qkv, the attention
+    output and its log-sum-exp, the pre-GELU and post-GELU FFN activations (about 230 MB per layer at B=32)."""
+
+    def __init__(self, params, cfg, device="cuda"):
+        super().__init__(params, cfg, device=device, dtype=torch.bfloat16)
+        D, Fd, n = cfg.dim, cfg.ffn, cfg.layers
+        if D // cfg.heads != 64:
+            raise OccError("XlsrFineTuner needs head_dim 64 (attention backward kernel)")
+        self.tshapes = []
+        for i in range(n):
+            self.tshapes += [("l%d.qkv.w" % i, (3 * D, D)), ("l%d.qkv.b" % i, (3 * D,)), ("l%d.o.w" % i, (D, D)), ("l%d.o.b" % i, (D,)),
+                             ("l%d.ln1.g" % i, (D,)), ("l%d.ln1.b" % i, (D,)), ("l%d.fc1.w" % i, (Fd, D)), ("l%d.fc1.b" % i, (Fd,)),
+                             ("l%d.fc2.w" % i, (D, Fd)), ("l%d.fc2.b" % i, (D,)), ("l%d.ln2.g" % i, (D,)), ("l%d.ln2.b" % i, (D,))]
+        self.tshapes += [("enc_ln.g", (D,)), ("enc_ln.b", (D,))]
+        off, self.tslots = 0, {}
+        for name, shp in self.tshapes:
+            nel = 1
+            for d in shp:
+                nel *= d
+            self.tslots[name] = (off, shp, nel)
+            off += (nel + 3) // 4 * 4
+        self.P = torch.empty(off, device=self.device, dtype=torch.float32)
+        self.G = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.mp = {k: self.P[o:o + nel].view(shp) for k, (o, shp, nel) in self.tslots.items()}
+        self.mg = {k: self.G[o:o + nel].view(shp) for k, (o, shp, nel) in self.tslots.items()}
+        self._load_master(params)
+        self.wT = {}
+        for name, shp in self.tshapes:
+            if name.endswith(".w"):
+                self.wT[name] = torch.empty(shp[1], shp[0], device=self.device, dtype=torch.bfloat16)
+                self.w[name] = torch.empty(shp, device=self.device, dtype=torch.bfloat16)
+            else:
+                self.w[name] = self.mp[name]                    # biases / LayerNorm affine are used in f32 directly
+        self.refresh_operands()
+        self.ctx = None
+
+    def _load_master(self, p):
+        with torch.no_grad():
+            for i in range(self.cfg.layers):
+                pre, a = "encoder.layers.%d" % i, "encoder.layers.%d.self_attn." % i
+                f = lambda t: t.detach().to(self.device, torch.float32)
+                self.mp["l%d.qkv.w" % i].copy_(torch.cat([f(p[a + "q_proj.weight"]), f(p[a + "k_proj.weight"]), f(p[a + "v_proj.weight"])], 0))
+                self.mp["l%d.qkv.b" % i].copy_(torch.cat([f(p[a + "q_proj.bias"]), f(p[a + "k_proj.bias"]), f(p[a + "v_proj.bias"])], 0))
+                self.mp["l%d.o.w" % i].copy_(f(p[a + "out_proj.weight"])); self.mp["l%d.o.b" % i].copy_(f(p[a + "out_proj.bias"]))
+                self.mp["l%d.ln1.g" % i].copy_(f(p[pre + ".self_attn_layer_norm.weight"])); self.mp["l%d.ln1.b" % i].copy_(f(p[pre + ".self_attn_layer_norm.bias"]))
+                self.mp["l%d.fc1.w" % i].copy_(f(p[pre + ".fc1.weight"])); self.mp["l%d.fc1.b" % i].copy_(f(p[pre + ".fc1.bias"]))
+                self.mp["l%d.fc2.w" % i].copy_(f(p[pre + ".fc2.weight"])); self.mp["l%d.fc2.b" % i].copy_(f(p[pre + ".fc2.bias"]))
+                self.mp["l%d.ln2.g" % i].copy_(f(p[pre + ".final_layer_norm.weight"])); self.mp["l%d.ln2.b" % i].copy_(f(p[pre + ".final_layer_norm.bias"]))
+            self.mp["enc_ln.g"].copy_(p["encoder.layer_norm.weight"].detach().to(self.device, torch.float32))
+            self.mp["enc_ln.b"].copy_(p["encoder.layer_norm.bias"].detach().to(self.device, torch.float32))
+
+    def refresh_operands(self):
+        """bf16 W and W^T from the f32 masters (after every optimizer step)."""
+        from .._lib import check, lib, ptr, stream_ptr
+        for name, shp in self.tshapes:
+            if name.endswith(".w"):
+                src = self.mp[name]
+                check(lib().occ_cast(ptr(src), OCC_F32, ptr(self.w[name]), dtype_code(self.w[name]), src.numel(), stream_ptr()), "occ_cast")
+                ops.transpose_bf16(src, self.wT[name], shp[0], shp[1], ld_src=shp[1], ld_dst=shp[0])
+
+    def export_params(self):
+        """Trainable tensors back under their fairseq names (q/k/v split again)."""
+        out, D = {}, self.cfg.dim
+        for i in range(self.cfg.layers):
+            pre, a = "encoder.layers.%d" % i, "encoder.layers.%d.self_attn." % i
+            w, b = self.mp["l%d.qkv.w" % i], self.mp["l%d.qkv.b" % i]
+            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                out[a + n + ".weight"] = w[j * D:(j + 1) * D].clone(); out[a + n + ".bias"] = b[j * D:(j + 1) * D].clone()
+            out[a + "out_proj.weight"] = self.mp["l%d.o.w" % i].clone(); out[a + "out_proj.bias"] = self.mp["l%d.o.b" % i].clone()
+            out[pre + ".self_attn_layer_norm.weight"] = self.mp["l%d.ln1.g" % i].clone(); out[pre + ".self_attn_layer_norm.bias"] = self.mp["l%d.ln1.b" % i].clone()
+            out[pre + ".fc1.weight"] = self.mp["l%d.fc1.w" % i].clone(); out[pre + ".fc1.bias"] = self.mp["l%d.fc1.b" % i].clone()
+            out[pre + ".fc2.weight"] = self.mp["l%d.fc2.w" % i].clone(); out[pre + ".fc2.bias"] = self.mp["l%d.fc2.b" % i].clone()
+            out[pre + ".final_layer_norm.weight"] = self.mp["l%d.ln2.g" % i].clone(); out[pre + ".final_layer_norm.bias"] = self.mp["l%d.ln2.b" % i].clone()
+        out["encoder.layer_norm.weight"] = self.mp["enc_ln.g"].clone(); out["encoder.layer_norm.bias"] = self.mp["enc_ln.b"].clone()
+        return out
+
+    def grad_dict(self):
+        out, D = {}, self.cfg.dim
+        for i in range(self.cfg.layers):
+            pre, a = "encoder.layers.%d" % i, "encoder.layers.%d.self_attn." % i
+            w, b = self.mg["l%d.qkv.w" % i], self.mg["l%d.qkv.b" % i]
+            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                out[a + n + ".weight"] = w[j * D:(j + 1) * D].clone(); out[a + n + ".bias"] = b[j * D:(j + 1) * D].clone()
+            out[a + "out_proj.weight"] = self.mg["l%d.o.w" % i].clone(); out[a + "out_proj.bias"] = self.mg["l%d.o.b" % i].clone()
+            out[pre + ".self_attn_layer_norm.weight"] = self.mg["l%d.ln1.g" % i].clone(); out[pre + ".self_attn_layer_norm.bias"] = self.mg["l%d.ln1.b" % i].clone()
+            out[pre + ".fc1.weight"] = self.mg["l%d.fc1.w" % i].clone(); out[pre + ".fc1.bias"] = self.mg["l%d.fc1.b" % i].clone()
+            out[pre + ".fc2.weight"] = self.mg["l%d.fc2.w" % i].clone(); out[pre + ".fc2.bias"] = self.mg["l%d.fc2.b" % i].clone()
+            out[pre + ".final_layer_norm.weight"] = self.mg["l%d.ln2.g" % i].clone(); out[pre + ".final_layer_norm.bias"] = self.mg["l%d.ln2.b" % i].clone()
+        out["encoder.layer_norm.weight"] = self.mg["enc_ln.g"].clone(); out["encoder.layer_norm.bias"] = self.mg["enc_ln.b"].clone()
+        return out
+
+    def _train_ws(self, B, L):
+        ws = self._workspace(B, L, slot=0)
+        if "tr" not in ws:
+            M, D, Fd = ws["M"], self.cfg.dim, self.cfg.ffn
+            Mp = (M + 63) // 64 * 64
+            bf, f32 = torch.bfloat16, torch.float32
+            e = lambda *s, dt=bf: torch.empty(*s, device=self.device, dtype=dt)
+            z = lambda *s: torch.zeros(*s, device=self.device, dtype=bf)
+            tr = {"Mp": Mp, "layers": []}
+            for _ in range(self.cfg.layers):
+                tr["layers"].append({"x_in": e(M, D, dt=f32), "h1": e(M, D), "qkv": e(M, 3 * D), "att": e(M, D), "lse": e(ws["M"] // ws["T"] * self.cfg.heads, ws["T"], dt=f32),
+                                     "x_mid": e(M, D, dt=f32), "h2": e(M, D), "u": e(M, Fd), "f": e(M, Fd)})
+            tr["x_out"] = e(M, D, dt=f32)
+            # transposed operand buffers (pad columns stay zero) and gradient activations
+            tr["tA_D"], tr["tB_D"] = z(D, Mp), z(D, Mp)
+            tr["tA_F"], tr["tB_F"] = z(Fd, Mp), z(Fd, Mp)
+            tr["tA_3D"] = z(3 * D, Mp)
+            tr["dx"] = e(M, D, dt=f32)
+            tr["du"], tr["dh"], tr["da"], tr["dqkv"] = e(M, Fd), e(M, D), e(M, D), e(M, 3 * D)
+            ws["tr"] = tr
+        return ws
+
+    def forward_train(self, wav):
+        """wav f32 [B,L] -> features f32 [B,T,dim]; keeps the tape for backward()."""
+        cfg, w = self.cfg, self.w
+        B, L = wav.shape
+        ws = self._train_ws(B, L)
+        tr = ws["tr"]
+        T, M, D, Fd = ws["T"], ws["M"], cfg.dim, cfg.ffn
+        with torch.no_grad():
+            self._frozen_prefix(wav, ws)                         # conv stack .. positional conv -> ws["x"] (f32 residual stream)
+        x = ws["x"]
+        code = OCC_BF16_CODE
+        xmap, hd = rowmap(M, 0, D), D // cfg.heads
+        for i in range(cfg.layers):
+            s = tr["layers"][i]
+            s["x_in"].copy_(x)
+            ops.layernorm(x, w["l%d.ln1.g" % i], w["l%d.ln1.b" % i], out=s["h1"])
+            ops.linear(s["h1"], w["l%d.qkv.w" % i], w["l%d.qkv.b" % i], out=s["qkv"])
+            ops.attention(s["qkv"], B, T, cfg.heads, hd, hd ** -0.5, out=s["att"], lse=s["lse"])
+            ops.gemm_raw(M, D, D, s["att"], xmap, w["l%d.o.w" % i], D, x, xmap, OCC_F32, code, bias=w["l%d.o.b" % i], R=x, r_map=xmap, r_dtype=OCC_F32)
+            s["x_mid"].copy_(x)
+            ops.layernorm(x, w["l%d.ln2.g" % i], w["l%d.ln2.b" % i], out=s["h2"])
+            ops.gemm_raw(M, Fd, D, s["h2"], xmap, w["l%d.fc1.w" % i], D, s["f"], rowmap(M, 0, Fd), code, code, bias=w["l%d.fc1.b" % i], act=ACT_GELU, aux=s["u"])
+            ops.gemm_raw(M, D, Fd, s["f"], rowmap(M, 0, Fd), w["l%d.fc2.w" % i], Fd, x, xmap, OCC_F32, code, bias=w["l%d.fc2.b" % i], R=x, r_map=xmap, r_dtype=OCC_F32)
+        tr["x_out"].copy_(x)
+        out = torch.empty(B, T, D, device=self.device, dtype=torch.float32)
+        ops.layernorm(x, w["enc_ln.g"], w["enc_ln.b"], out=out.view(M, D))
+        self.ctx = (B, L)
+        return out
+
+    def _frozen_prefix(self, wav, ws):
+        """Conv feature extractor, LayerNorm, projection, positional conv (frozen): fills ws["x"]."""
+        cfg, w, dt = self.cfg, self.w, self.dtype
+        wav = wav.to(self.device, torch.float32).contiguous()
+        B, L = wav.shape
+        Ts, T, M = ws["Ts"], ws["T"], ws["M"]
+        code = dtype_code(ws["h"])
+        D = cfg.dim
+        cur, nxt = ws["cA"], ws["cB"]
+        ops.conv0_ln_gelu(wav, w["c0.w"], w["c0.b"], w["c0.g"], w["c0.be"], 10, 5, dt, out=cur[: B * Ts[0] * 512].view(B, Ts[0], 512))
+        Tin = Ts[0]
+        for i in range(1, 7):
+            _, k, s = CONV_LAYERS[i]
+            Tout = Ts[i]
+            o = nxt[: B * Tout * 512].view(B * Tout, 512)
+            ops.gemm_raw(B * Tout, 512, k * 512, cur, rowmap(Tout, Tin * 512, s * 512), w["c%d.w" % i], k * 512, o, rowmap(B * Tout, 0, 512), code, code, bias=w["c%d.b" % i])
+            ops.layernorm(o, w["c%d.g" % i], w["c%d.be" % i], gelu=True, out=o)
+            cur, nxt = nxt, cur
+            Tin = Tout
+        ops.layernorm(cur[: M * 512].view(M, 512), w["ln.g"], w["ln.b"], out=ws["feat"])
+        xpad = ws["xpad"]
+        Tp, half = T + cfg.pos_k, cfg.pos_k // 2
+        inner = xpad.data_ptr() + half * D * xpad.element_size()
+        pmap = rowmap(T, Tp * D, D)
+        ops.gemm_raw(M, D, 512, ws["feat"], rowmap(M, 0, 512), w["proj.w"], 512, inner, pmap, code, code, bias=w["proj.b"])
+        G = cfg.pos_groups
+        cg = D // G
+        ops.gemm_raw(M, cg, cfg.pos_k * cg, xpad, pmap, w["pos.w"], cfg.pos_k * cg, ws["x"], rowmap(M, 0, D), OCC_F32, code, bias=w["pos.b"], act=ACT_GELU,
+                     R=inner, r_map=pmap, r_dtype=code, a_seg=(cfg.pos_k, cg, D), groups=(G, cg, cg * cfg.pos_k * cg, cg))
+
+    def zero_grad(self):
+        from .. import backend_ops as K
+        K.fill(self.G, 0.0)
+
+    def _wgrad(self, dy, x, N, Kd, M, Mp, tA, tB, gname, bias_name):
+        """G[gname] [N,Kd] += dy^T x ; G[bias] += colsum(dy).  dy [M,N], x [M,Kd] (f32 or bf16)."""
+        from .. import backend_ops as K
+        ops.transpose_bf16(dy, tA, M, N, ld_src=N, ld_dst=Mp)
+        ops.transpose_bf16(x, tB, M, Kd, ld_src=Kd, ld_dst=Mp)
+        g = self.mg[gname]
+        ops.gemm_raw(N, Kd, Mp, tA, rowmap(N, 0, Mp), tB, Mp, g, rowmap(N, 0, Kd), OCC_F32, OCC_BF16_CODE, R=g, r_map=rowmap(N, 0, Kd), r_dtype=OCC_F32)
+        K.colsum(dy, rowmap(M, 0, N), M, N, self.mg[bias_name])
+
+    def backward(self, dfeats):
+        """dfeats f32 [B,T,dim] (gradient wrt the returned features) -> accumulates into self.G."""
+        if self.ctx is None:
+            raise OccError("backward() needs a preceding forward_train()")
+        cfg, w = self.cfg, self.w
+        B, L = self.ctx
+        ws = self._workspace(B, L, slot=0)
+        tr = ws["tr"]
+        T, M, D, Fd, Mp = ws["T"], ws["M"], cfg.dim, cfg.ffn, tr["Mp"]
+        bfc, hd = OCC_BF16_CODE, D // cfg.heads
+        xmap, fmap, qmap = rowmap(M, 0, D), rowmap(M, 0, Fd), rowmap(M, 0, 3 * D)
+        dx = tr["dx"]
+        ops.layernorm_bwd(dfeats.contiguous().view(M, D), tr["x_out"], w["enc_ln.g"], None, dx, self.mg["enc_ln.g"], self.mg["enc_ln.b"])
+        for i in range(cfg.layers - 1, -1, -1):
+            s = tr["layers"][i]
+            # ---- FFN: x3 = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+            self._wgrad(dx, s["f"], D, Fd, M, Mp, tr["tA_D"], tr["tB_F"], "l%d.fc2.w" % i, "l%d.fc2.b" % i)
+            ops.gemm_raw(M, Fd, D, dx, xmap, self.wT["l%d.fc2.w" % i], D, tr["du"], fmap, bfc, OCC_AF32_WBF16, act=ACT_GELU_GRAD, aux=s["u"])
+            self._wgrad(tr["du"], s["h2"], Fd, D, M, Mp, tr["tA_F"], tr["tB_D"], "l%d.fc1.w" % i, "l%d.fc1.b" % i)
+            ops.gemm_raw(M, D, Fd, tr["du"], fmap, self.wT["l%d.fc1.w" % i], Fd, tr["dh"], xmap, bfc, bfc)
+            ops.layernorm_bwd(tr["dh"], s["x_mid"], w["l%d.ln2.g" % i], dx, dx, self.mg["l%d.ln2.g" % i], self.mg["l%d.ln2.b" % i])
+            # ---- attention: x_mid = x_in + out_proj(attn(qkv(LN1(x_in))))
+            self._wgrad(dx, s["att"], D, D, M, Mp, tr["tA_D"], tr["tB_D"], "l%d.o.w" % i, "l%d.o.b" % i)
+            ops.gemm_raw(M, D, D, dx, xmap, self.wT["l%d.o.w" % i], D, tr["da"], xmap, bfc, OCC_AF32_WBF16)
+            ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
+            self._wgrad(tr["dqkv"], s["h1"], 3 * D, D, M, Mp, tr["tA_3D"], tr["tB_D"], "l%d.qkv.w" % i, "l%d.qkv.b" % i)
+            ops.gemm_raw(M, D, 3 * D, tr["dqkv"], qmap, self.wT["l%d.qkv.w" % i], 3 * D, tr["dh"], xmap, bfc, bfc)
+            ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i])
+        self.ctx = None

@@ -103,14 +103,39 @@ def conv0_ln_gelu(wav, w, bias, gamma, beta, k, stride, out_dtype, eps=1e-5, out
     return out
 
 
-def attention(qkv, B, T, H, hd, scale, out=None):
+def attention(qkv, B, T, H, hd, scale, out=None, lse=None):
+    """lse: optional f32 [B*H, T] output (log2-sum-exp2 of the scaled scores) kept for attention_bwd."""
     _dev(qkv)
     D = H * hd
     assert qkv.shape == (B * T, 3 * D) and qkv.is_contiguous()
     if out is None:
         out = torch.empty(B * T, D, device=qkv.device, dtype=qkv.dtype)
-    check(lib().occ_attention(ptr(qkv), ptr(out), dtype_code(qkv), B, T, H, hd, 3 * D, D, float(scale), stream_ptr()), "occ_attention")
+    check(lib().occ_attention(ptr(qkv), ptr(out), dtype_code(qkv), B, T, H, hd, 3 * D, D, float(scale), ptr(lse), stream_ptr()), "occ_attention")
     return out
+
+
+def attention_bwd(qkv, o, dout, lse, B, T, H, hd, scale, dqkv=None):
+    D = H * hd
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    check(lib().occ_attention_bwd(ptr(qkv), ptr(o), ptr(dout), ptr(lse), ptr(dqkv), B, T, H, hd, 3 * D, D, float(scale), stream_ptr()),
+          "occ_attention_bwd")
+    return dqkv
+
+
+def transpose_bf16(src, dst, rows, cols, ld_src=None, ld_dst=None):
+    """dst[c, r] = bf16(src[r, c]); dst is a bf16 [cols, ld_dst] buffer whose pad columns the caller keeps at zero."""
+    check(lib().occ_transpose_bf16(ptr(src), dtype_code(src), ptr(dst), int(rows), int(cols), int(ld_src or cols), int(ld_dst or dst.shape[-1]),
+                                   stream_ptr()), "occ_transpose_bf16")
+    return dst
+
+
+def layernorm_bwd(dy, x, gamma, dres, dx, dgamma, dbeta, eps=1e-5):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    check(lib().occ_layernorm_bwd(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(dres), ptr(dx), ptr(dgamma), ptr(dbeta), rows, C, float(eps),
+                                  stream_ptr()), "occ_layernorm_bwd")
+    return dx
 
 
 # ---------------------------------------------------------------------------------- RawBoost ---

@@ -1,0 +1,128 @@
+"""Backward of the XLS-R transformer encoder on HIP (fine-tuning path) vs torch autograd on the CPU oracle.
+bf16 operands / f32 accumulation: gradients are compared by cosine and by max error relative to the tensor's max."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _r(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _close(got, ref, cos_min=0.999, rel=3e-2, name=""):
+    got, ref = got.float().cpu().reshape(-1), ref.float().reshape(-1)
+    cos = float((got * ref).sum() / (got.norm() * ref.norm() + 1e-30))
+    err = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+    assert cos > cos_min and err < rel, (name, cos, err)
+
+
+@pytest.mark.parametrize("rows,cols,dt", [(6368, 1024, torch.float32), (199, 64, torch.bfloat16), (70, 130, torch.float32)])
+def test_transpose_bf16(rows, cols, dt):
+    from occm_amd import ops
+    x = _r(rows, cols, seed=1).to(dt)
+    ld = (rows + 63) // 64 * 64
+    dst = torch.zeros(cols, ld, dtype=torch.bfloat16, device="cuda")
+    ops.transpose_bf16(x.cuda(), dst, rows, cols)
+    torch.testing.assert_close(dst[:, :rows].cpu().float(), x.bfloat16().float().T)
+    assert float(dst[:, rows:].abs().max()) == 0.0 if ld > rows else True
+
+
+@pytest.mark.parametrize("C", [256, 1024, 1280])
+def test_layernorm_bwd(C):
+    from occm_amd import ops
+    rows = 523
+    x = (_r(rows, C, seed=2) * 2 + 0.3).requires_grad_(True)
+    g, b = (1 + 0.1 * _r(C, seed=3)).requires_grad_(True), (0.1 * _r(C, seed=4)).requires_grad_(True)
+    dy, dres = _r(rows, C, seed=5), _r(rows, C, seed=6)
+    F.layer_norm(x, (C,), g, b).backward(dy)
+    dx = torch.empty(rows, C, device="cuda")
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.layernorm_bwd(dy.cuda(), x.detach().cuda(), g.detach().cuda(), dres.cuda(), dx, dg, db)
+    torch.testing.assert_close(dx.cpu(), x.grad + dres, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dg.cpu(), g.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3)
+    dyb = dy.bfloat16()
+    dx2 = torch.empty(rows, C, device="cuda")
+    ops.layernorm_bwd(dyb.cuda(), x.detach().cuda(), g.detach().cuda(), None, dx2, dg, db)
+    x.grad = None
+    F.layer_norm(x, (C,), g, b).backward(dyb.float())
+    torch.testing.assert_close(dx2.cpu(), x.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 199, 4), (1, 37, 2), (2, 256, 1), (1, 64, 3)])
+def test_attention_fwd_lse_and_bwd(B, T, H):
+    from occm_amd import ops
+    hd, D = 64, H * 64
+    qkv = _r(B * T, 3 * D, seed=7).bfloat16()
+    do = _r(B * T, D, seed=8).bfloat16()
+    x = qkv.float().requires_grad_(True)
+    q, k, v = [t.view(B, T, H, hd).transpose(1, 2) for t in x.split(D, dim=1)]
+    s = q @ k.transpose(-1, -2) * hd ** -0.5
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * T, D)
+    ref.backward(do.float())
+    lse = torch.empty(B * H, T, device="cuda")
+    out = ops.attention(qkv.cuda(), B, T, H, hd, hd ** -0.5, lse=lse)
+    torch.testing.assert_close(out.cpu().float(), ref.detach(), rtol=1e-2, atol=1e-2)
+    ref_lse = torch.logsumexp(s.detach(), -1).reshape(B * H, T) * 1.4426950408889634
+    torch.testing.assert_close(lse.cpu(), ref_lse, rtol=1e-3, atol=2e-3)
+    dqkv = ops.attention_bwd(qkv.cuda(), out, do.cuda(), lse, B, T, H, hd, hd ** -0.5)
+    for j, n in enumerate("qkv"):
+        _close(dqkv[:, j * D:(j + 1) * D], x.grad[:, j * D:(j + 1) * D], cos_min=0.998, rel=4e-2, name="d" + n)
+
+
+def test_gemm_gelu_aux_and_gelu_grad_epilogues_and_mixed_operands():
+    from occm_amd import ops
+    M, N, Kd = 300, 512, 256
+    x, w, b = _r(M, Kd, seed=9).bfloat16(), _r(N, Kd, seed=10, scale=Kd ** -0.5).bfloat16(), _r(N, seed=11)
+    u_ref = x.float() @ w.float().T + b
+    f = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"); u = torch.empty_like(f)
+    ops.gemm_raw(M, N, Kd, x.cuda(), ops.rowmap(M, 0, Kd), w.cuda(), Kd, f, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16, bias=b.cuda(), act=ops.ACT_GELU, aux=u)
+    torch.testing.assert_close(u.cpu().float(), u_ref, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(f.cpu().float(), F.gelu(u_ref), rtol=1e-2, atol=1e-2)
+    # du = (dy @ W2) * gelu'(u) with f32 dy and bf16 W2^T
+    dy, w2t = _r(M, Kd, seed=12), _r(N, Kd, seed=13, scale=Kd ** -0.5).bfloat16()
+    uu = u.cpu().float().requires_grad_(True)
+    F.gelu(uu).backward(dy.bfloat16().float() @ w2t.float().T)
+    du = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_raw(M, N, Kd, dy.cuda(), ops.rowmap(M, 0, Kd), w2t.cuda(), Kd, du, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_AF32_WBF16, act=ops.ACT_GELU_GRAD, aux=u)
+    _close(du, uu.grad, cos_min=0.9995, rel=2e-2, name="gelu_grad")
+
+
+@pytest.mark.parametrize("L", [4000, 16000])
+def test_finetuner_gradients_match_oracle_autograd(L):
+    from oracle import xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.models import xlsr
+    kw = dict(dim=256, ffn=512, heads=4, layers=2)
+    rcfg, cfg = xlsr_ref.XlsrConfig(**kw), xlsr.XlsrConfig(**kw)
+    p = fill_like(xlsr_ref.param_shapes(rcfg), seed=3)
+    train_keys = [k for k in p if k.startswith("encoder.layers.") or k.startswith("encoder.layer_norm")]
+    for k in train_keys:
+        p[k].requires_grad_(True)
+    wav = 0.1 * _r(2, L, seed=5)
+    ref = xlsr_ref.extract_feat(wav, p, rcfg)
+    dfe = _r(*ref.shape, seed=6)
+    (ref * dfe).sum().backward()
+    ft = xlsr.XlsrFineTuner({k: v.detach() for k, v in p.items()}, cfg)
+    out = ft.forward_train(wav.cuda())
+    err = (out.cpu() - ref.detach()).abs()
+    assert float(err.max()) < 8e-2 and float(err.mean()) < 1.2e-2, (float(err.max()), float(err.mean()))
+    ft.zero_grad()
+    ft.backward(dfe.cuda())
+    grads = ft.grad_dict()
+    assert set(grads) == set(train_keys)
+    bad = []
+    for k in train_keys:
+        g, r = grads[k].cpu().reshape(-1), p[k].grad.reshape(-1)
+        cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-30))
+        rel = float((g - r).abs().max() / (r.abs().max() + 1e-30))
+        if cos < 0.995 or rel > 6e-2:
+            bad.append((k, round(cos, 5), round(rel, 4)))
+    assert not bad, bad[:10]
+    # the exported parameters still carry the fairseq names / split q,k,v
+    ex = ft.export_params()
+    for k in train_keys:
+        torch.testing.assert_close(ex[k].cpu(), p[k].detach())
