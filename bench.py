@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the frozen front-end from a HIP graph")
+    ap.add_argument("--finetune", action="store_true", help="NOT the headline config: also train the XLS-R transformer encoder "
+                    "(BASELINE configs[2] minus the conv-stack backward and RawBoost); prints the same JSON with a different workload name")
+    ap.add_argument("--bs", type=int, default=BS, help="per-GPU batch (headline: 32)")
     ap.add_argument("--split", type=int, default=1, help="run the front-end as this many concurrent sub-batches on separate HIP "
                     "streams inside the graph; measured slower on MI355X (16.4 / 19.8 / 21.9 ms per step at 1 / 2 / 4), kept for experiments")
     args = ap.parse_args()
@@ -137,11 +140,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = xlsr.XlsrConfig.xlsr_300m()
-    model = AModel(None, dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, seed=0)
+    bs = args.bs
+    model = AModel(None, dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, seed=0, finetune_ssl=args.finetune)
     model.train()
-    trainer = OcTrainer(model, lr=1e-5, w_compact=0.0, w_descr=1.0)
-    wav, labels = synth_batch(BS, rank, dev)
+    trainer = OcTrainer(model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=args.finetune)
+    wav, labels = synth_batch(bs, rank, dev)
     fe = model.ssl_model.model
+    if args.finetune:
+        args.no_graph = True
 
     # The frozen front-end is a fixed launch sequence: capture it once into a HIP graph (launch-bound otherwise).
     graph = None
@@ -150,8 +156,8 @@ def main():
         orig_forward = fe.forward
         nsplit = max(1, args.split)
         T = xlsr.n_frames(L_SAMPLES)
-        static_feats = torch.empty(BS, T, cfg.dim, device=dev, dtype=torch.float32)
-        cuts = [BS * i // nsplit for i in range(nsplit + 1)]
+        static_feats = torch.empty(bs, T, cfg.dim, device=dev, dtype=torch.float32)
+        cuts = [bs * i // nsplit for i in range(nsplit + 1)]
         side = [torch.cuda.Stream(device=dev) for _ in range(nsplit - 1)]
 
         def split_forward():
@@ -189,7 +195,7 @@ def main():
 
     # ---- roofline of the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / measured launch time ----
     roof = None
-    if rank == 0:
+    if rank == 0 and not args.finetune:
         if graph is not None:
             fe.forward = orig_forward
         ops.PROFILE = []
@@ -199,7 +205,7 @@ def main():
         recs, ops.PROFILE = ops.PROFILE, None
         t_ms = sum(a.elapsed_time(b) for kind, a, b in recs if kind == "gemm_bf16") / 3.0
         n_launch = sum(1 for kind, _, _ in recs if kind == "gemm_bf16") // 3
-        fl = gemm_flops_per_utt(cfg, L_SAMPLES) * BS
+        fl = gemm_flops_per_utt(cfg, L_SAMPLES) * bs
         ach = fl / (t_ms * 1e-3) / 1e12
         traffic, tnote = None, None
         try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
@@ -210,17 +216,19 @@ def main():
             pass
         roof = {"kernel": "gemm_bf16_dma_kernel (all front-end Linear/Conv1d launches of one step)", "bound": "mfma",
                 "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": tnote, "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(cfg, L_SAMPLES, BS) / max(n_launch, 1)),
+                "traffic": traffic, "traffic_source": tnote, "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(cfg, L_SAMPLES, bs) / max(n_launch, 1)),
                 "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / max(n_launch, 1), 2), "flops_per_step": fl}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
-        out = {"metric": "utterances/sec (4 s @16 kHz) training step", "value": round(BS * world * args.steps / dt, 2), "unit": "utterances/s",
+        wl = ("XLSR-300M frozen frontend + AASIST backend, bs=%d per GPU, 64000-sample utterances (BASELINE configs[1])" % bs) if not args.finetune else \
+            ("XLSR-300M with TRAINABLE transformer encoder (conv stack frozen) + AASIST backend, bs=%d per GPU (towards BASELINE configs[2])" % bs)
+        out = {"metric": "utterances/sec (4 s @16 kHz) training step", "value": round(bs * world * args.steps / dt, 2), "unit": "utterances/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "XLSR-300M frozen frontend + AASIST backend, bs=32 per GPU, 64000-sample utterances (BASELINE configs[1])",
-                          "global_batch": BS * world, "samples_per_utt": L_SAMPLES, "parallelism": "dp%d" % world,
+               "config": {"workload": wl,
+                          "global_batch": bs * world, "samples_per_utt": L_SAMPLES, "parallelism": "dp%d" % world,
                           "frontend": "bf16 MFMA, f32 accumulate, HIP-graph replay", "backend": "fwd+bwd, f32 storage, bf16-MFMA GEMMs (f32 accumulate), f32 wgrad, dropout on, Adam lr=1e-5",
                           "loss": "0.0*compactness + 1.0*descriptiveness (oc_training.py:380-381)", "final_loss_d": round(loss_d, 5)},
                "roofline": roof, "cpu_baseline": cpu}

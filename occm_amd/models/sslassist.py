@@ -672,10 +672,10 @@ class AModel(torch.nn.Module):
     deterministic synthetic filler because no checkpoint exists offline (the reference hard-codes a path, :24)."""
 
     def __init__(self, args=None, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, backend_state_dict=None, seed=0,
-                 backend_compute=None):
+                 backend_compute=None, finetune_ssl=False):
         super().__init__()
         self.device = device
-        self.ssl_model = SSLModel(device, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, seed=seed)
+        self.ssl_model = SSLModel(device, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, seed=seed, finetune=finetune_ssl)
         if backend_compute is None:
             backend_compute = "bf16" if ssl_dtype == torch.bfloat16 else "f32"
         self.backend = AasistBackend(backend_state_dict, device=device, seed=seed, compute=backend_compute)
@@ -690,7 +690,10 @@ class AModel(torch.nn.Module):
 
     def state_dict(self, *a, **kw):
         sd = self.backend.state_dict()
-        for k, v in self.ssl_model._params.items():
+        ssl = dict(self.ssl_model._params)
+        if getattr(self.ssl_model, "finetune", False):
+            ssl.update(self.ssl_model.model.export_params())        # trained encoder tensors, fairseq names
+        for k, v in ssl.items():
             sd["ssl_model.model." + k] = v
         return sd
 

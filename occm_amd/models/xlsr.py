@@ -216,7 +216,7 @@ class SSLModel(torch.nn.Module):
     weights come from ``state_dict`` (fairseq names), a ``cp_path`` torch file holding them, or -- when
     neither is given -- the deterministic synthetic filler (no checkpoint can exist offline)."""
 
-    def __init__(self, device="cuda", cp_path=None, state_dict=None, cfg=None, dtype=torch.bfloat16, seed=0):
+    def __init__(self, device="cuda", cp_path=None, state_dict=None, cfg=None, dtype=torch.bfloat16, seed=0, finetune=False):
         super().__init__()
         self.device = device
         self.cfg = cfg or XlsrConfig.xlsr_300m()
@@ -230,7 +230,11 @@ class SSLModel(torch.nn.Module):
         missing = set(param_shapes(self.cfg)) - set(self._params)
         if missing:
             raise OccError("XLS-R state_dict lacks %d tensors, e.g. %s" % (len(missing), sorted(missing)[:3]))
-        self.model = XlsrFrontend(self._params, self.cfg, device=device, dtype=dtype)
+        self.finetune = finetune
+        if finetune:        # the reference's optimizer holds the SSL parameters too (oc_training.py:324): trainable encoder
+            self.model = XlsrFineTuner(self._params, self.cfg, device=device)
+        else:
+            self.model = XlsrFrontend(self._params, self.cfg, device=device, dtype=dtype)
 
     def extract_feat(self, input_data):
         with torch.no_grad():

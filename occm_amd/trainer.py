@@ -11,20 +11,27 @@ class OcTrainer:
     the SE-ResNet script uses 0.1 / 0.9 (test_dataloader_v2.py:127)."""
 
     def __init__(self, model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=False, group_size=None):
-        if train_frontend:
-            raise NotImplementedError("fine-tuning the XLS-R front-end (backward through the transformer) is not built yet")
         self.model = model
         self.be = model.backend
+        self.fe = model.ssl_model.model
+        self.train_frontend = train_frontend
+        if train_frontend and not hasattr(self.fe, "forward_train"):
+            raise ValueError("train_frontend=True needs AModel(..., finetune_ssl=True)")
         self.w_c, self.w_d = w_compact, w_descr
         self.group_size = group_size
-        self.opt = ops.AdamMulti([self.be.P], lr=lr)
-        self._grads = [self.be.G]
-        self.reducer = FlatGradAllReducer(self.be.G)
+        params, self._grads = [self.be.P], [self.be.G]
+        if train_frontend:                     # transformer encoder of XLS-R is trained; the conv stack stays frozen this round
+            params.append(self.fe.P); self._grads.append(self.fe.G)
+        self.opt = ops.AdamMulti(params, lr=lr)
+        self.reducers = [FlatGradAllReducer(g) for g in self._grads]
+        self.reducer = self.reducers[0]
         self.last = None
 
     def step(self, wav, labels):
         """wav f32 [B,L] cuda, labels i64 [B] cuda.  Returns device tensors (loss_c, loss_d); no host sync."""
         be = self.be
+        if self.train_frontend:
+            return self._step_finetune(wav, labels)
         feats = self.model.ssl_model.model.forward(wav, out_dtype=torch.float32)
         be.zero_grad()
         emb, logits = be.forward(feats, train=True)
@@ -35,5 +42,23 @@ class OcTrainer:
         be.backward(demb, dlog)
         self.reducer.all_reduce()
         self.opt.step(self._grads, grad_scale=self.reducer.grad_scale)
+        self.last = (lc, ld)
+        return lc, ld
+
+    def _step_finetune(self, wav, labels):
+        be, fe = self.be, self.fe
+        feats = fe.forward_train(wav)
+        be.zero_grad(); fe.zero_grad()
+        emb, logits = be.forward(feats, train=True)
+        B = emb.shape[0]
+        ng = 1 if not self.group_size else B // self.group_size
+        lc, demb = ops.compactness_loss(emb, n_groups=ng, group=self.group_size or B, scale=self.w_c, want_grad=True)
+        ld, dlog = ops.ce_loss(logits, labels, scale=self.w_d, want_grad=True)
+        dfeats = be.backward(demb, dlog, want_dfeats=True)
+        fe.backward(dfeats)
+        for r in self.reducers:
+            r.all_reduce()
+        self.opt.step(self._grads, grad_scale=self.reducer.grad_scale)
+        fe.refresh_operands()
         self.last = (lc, ld)
         return lc, ld

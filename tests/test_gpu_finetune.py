@@ -115,8 +115,14 @@ def test_finetuner_gradients_match_oracle_autograd(L):
     grads = ft.grad_dict()
     assert set(grads) == set(train_keys)
     bad = []
+    gmax = max(float(p[k].grad.abs().max()) for k in train_keys)
     for k in train_keys:
         g, r = grads[k].cpu().reshape(-1), p[k].grad.reshape(-1)
+        if float(r.abs().max()) < 1e-5 * gmax:
+            # exactly-zero gradients in exact arithmetic (k_proj.bias: softmax is invariant to a per-query score shift);
+            # the reference holds f32 noise there, the bf16 path bf16 noise
+            assert float(g.abs().max()) < 2e-2 * gmax, (k, float(g.abs().max()), gmax)
+            continue
         cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-30))
         rel = float((g - r).abs().max() / (r.abs().max() + 1e-30))
         if cos < 0.995 or rel > 6e-2:
@@ -126,3 +132,29 @@ def test_finetuner_gradients_match_oracle_autograd(L):
     ex = ft.export_params()
     for k in train_keys:
         torch.testing.assert_close(ex[k].cpu(), p[k].detach())
+
+
+def test_finetune_trainer_runs_and_learns():
+    """A few fused steps (front-end encoder + back-end trained, Adam on both flat buffers): the loss on a fixed batch falls,
+    encoder weights move, and state_dict() carries the updated tensors under the fairseq names."""
+    from occm_amd.models import xlsr
+    from occm_amd.models.sslassist import AModel
+    from occm_amd.trainer import OcTrainer
+    cfg = xlsr.XlsrConfig(dim=1024, ffn=512, heads=16, layers=2)      # AASIST's LL expects 1024-d features
+    model = AModel(None, "cuda", ssl_cfg=cfg, finetune_ssl=True, backend_compute="f32")
+    before = {k: v.clone() for k, v in model.ssl_model.model.export_params().items()}
+    tr = OcTrainer(model, lr=2e-4, w_compact=0.1, w_descr=0.9, train_frontend=True)
+    wav = (0.1 * _r(12, 16000, seed=1)).cuda()
+    labels = (torch.arange(12) % 12 >= 6).long().cuda()
+    losses = []
+    for _ in range(8):
+        lc, ld = tr.step(wav, labels)
+        losses.append(0.1 * float(lc) + 0.9 * float(ld))
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    sd = model.state_dict()
+    moved = 0
+    for k, v in before.items():
+        assert "ssl_model.model." + k in sd
+        moved += int(not torch.equal(sd["ssl_model.model." + k].cpu(), v.cpu()))
+    assert moved == len(before)
