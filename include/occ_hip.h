@@ -246,11 +246,13 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
 /* ---- backward of the transformer encoder (fine-tuning; autograd of fairseq's pre-LN TransformerSentenceEncoderLayer) ---- */
 /* dst[c, r] = bf16(src[r, c]) (src f32 or bf16 [rows, ld_src], dst bf16 [cols, ld_dst >= rows]): K-contiguous operands for the
  * weight-gradient GEMMs dW = dY^T X, which then run on the same bf16 MFMA GEMM as the forward.                */
+/* colsum (optional f32 [cols]): += column sums of src -- the bias gradient comes for free with the dY^T operand.           */
 int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
-                       void* stream);
+                       float* colsum, void* stream);
 /* dx = LayerNorm'(x)^T dy (+ dres, the residual-branch gradient; dx may alias dres); dgamma += sum dy*xhat; dbeta += sum dy. */
-int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, float* dgamma,
-                      float* dbeta, int64_t rows, int64_t C, float eps, void* stream);
+/* dx_bf16 (optional): a bf16 copy of dx for the next input-gradient GEMMs.                                             */
+int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16,
+                      float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, void* stream);
 /* dq|dk|dv (bf16 [B*T, 3D], same layout as qkv) of softmax(scale q.k^T) v given o (forward output), dout and the forward's lse.
  * head_dim 64, T <= 256.                                                                                     */
 int occ_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H,

@@ -13,8 +13,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 // dst[c][r] = bf16(src[r][c]); dst rows have ld_dst >= rows elements (pad columns are left untouched: callers keep them 0).
 template <typename TS>
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const TS* __restrict__ src, unsigned short* __restrict__ dst, long long rows, long long cols,
-                                                            long long ld_src, long long ld_dst) {
+                                                            long long ld_src, long long ld_dst, float* __restrict__ colsum) {
     __shared__ unsigned short tile[64][66];
+    __shared__ float csum[4][64];
+    float cs = 0.f;
     const long long r0 = (long long)blockIdx.y * 64, c0 = (long long)blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll 4
@@ -22,12 +24,14 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const TS* __restric
         const long long r = r0 + ty + 4 * i, c = c0 + tx;
         unsigned short v = 0;
         if (r < rows && c < cols) {
-            if (sizeof(TS) == 4) v = f32_to_bf16_bits(reinterpret_cast<const float*>(src)[r * ld_src + c]);
-            else v = reinterpret_cast<const unsigned short*>(src)[r * ld_src + c];
+            if (sizeof(TS) == 4) { const float f = reinterpret_cast<const float*>(src)[r * ld_src + c]; cs += f; v = f32_to_bf16_bits(f); }
+            else { v = reinterpret_cast<const unsigned short*>(src)[r * ld_src + c]; cs += bf16_bits_to_f32(v); }
         }
         tile[ty + 4 * i][tx] = v;
     }
+    if (colsum) csum[ty][tx] = cs;
     __syncthreads();
+    if (colsum && ty == 0 && c0 + tx < cols) atomicAdd(colsum + c0 + tx, csum[0][tx] + csum[1][tx] + csum[2][tx] + csum[3][tx]);
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const long long c = c0 + ty + 4 * i, r = r0 + tx;
@@ -38,18 +42,36 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const TS* __restric
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward over rows of width C (C % 8 == 0, C <= 2048), one wave per row, persistent waves:
 //   dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) (+ dres);  dgamma += sum dy*xhat;  dbeta += sum dy.
+template <typename T> struct LVec8;
+template <> struct LVec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+};
+template <> struct LVec8<unsigned short> {
+    static __device__ __forceinline__ void load(const unsigned short* p, float (&v)[8]) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+};
+
 template <typename TDY, int NIT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
-                                                           const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, long long rows, int C, float eps) {
-    const int lane = threadIdx.x & 63;
-    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+                                                           const float* __restrict__ dres, float* __restrict__ dx, unsigned short* __restrict__ dx_bf16,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, long long rows, int C, float eps) {
+    __shared__ float red[3][2][NIT * 512];           // waves 1..3 park their partial dgamma / dbeta here
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long wave0 = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
     float dg[NIT][8], db[NIT][8], g[NIT][8];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int c = (it * 64 + lane) * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; g[it][e] = c < C ? gamma[c + e] : 0.f; }
+        for (int e = 0; e < 8; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; g[it][e] = 0.f; }
+        if (c < C) LVec8<float>::load(gamma + c, g[it]);
     }
     for (long long row = wave0; row < rows; row += nwaves) {
         float xv[NIT][8], dv[NIT][8];
@@ -57,12 +79,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c = (it * 64 + lane) * 8;
+            if (c < C) {
+                LVec8<float>::load(x + row * C + c, xv[it]);
+                LVec8<TDY>::load(dy + row * C + c, dv[it]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                xv[it][e] = c < C ? x[row * C + c + e] : 0.f;
-                dv[it][e] = c < C ? occ_load_f32(dy + row * C + c + e) : 0.f;
-                s += xv[it][e];
+                for (int e = 0; e < 8; ++e) { xv[it][e] = 0.f; dv[it][e] = 0.f; }
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += xv[it][e];
         }
         const float mean = wave_sum(s) / (float)C;
         float q = 0.f;
@@ -82,7 +107,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
             for (int e = 0; e < 8; ++e) {
                 const float xh = (xv[it][e] - mean) * rstd;
                 const float dxh = dv[it][e] * g[it][e];
-                xv[it][e] = xh;                    // keep xhat
+                xv[it][e] = xh;                    // keep xhat (zero-gamma padding lanes contribute nothing)
                 s1 += dxh; s2 += dxh * xh;
                 dg[it][e] += dv[it][e] * xh; db[it][e] += dv[it][e];
             }
@@ -91,21 +116,45 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
         for (int it = 0; it < NIT; ++it) {
             const int c = (it * 64 + lane) * 8;
             if (c < C) {
+                float v[8], r[8];
+                if (dres) LVec8<float>::load(dres + row * C + c, r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float v = rstd * (dv[it][e] * g[it][e] - s1 - xv[it][e] * s2);
-                    if (dres) v += dres[row * C + c + e];
-                    dx[row * C + c + e] = v;
+                    v[e] = rstd * (dv[it][e] * g[it][e] - s1 - xv[it][e] * s2);
+                    if (dres) v[e] += r[e];
+                }
+                *reinterpret_cast<float4*>(dx + row * C + c) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dx + row * C + c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                if (dx_bf16) {
+                    unsigned w[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+                    *reinterpret_cast<uint4*>(dx_bf16 + row * C + c) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
         }
     }
+    // one set of atomics per workgroup: waves 1..3 hand their partials to wave 0 through LDS
+    if (wave > 0) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int c = (it * 64 + lane) * 8;
-        if (c < C) {
+        for (int it = 0; it < NIT; ++it)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { atomicAdd(dgamma + c + e, dg[it][e]); atomicAdd(dbeta + c + e, db[it][e]); }
+            for (int e = 0; e < 8; ++e) { red[wave - 1][0][(it * 64 + lane) * 8 + e] = dg[it][e]; red[wave - 1][1][(it * 64 + lane) * 8 + e] = db[it][e]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 8;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a = dg[it][e], bb = db[it][e];
+#pragma unroll
+                    for (int w2 = 0; w2 < 3; ++w2) { a += red[w2][0][c + e]; bb += red[w2][1][c + e]; }
+                    atomicAdd(dgamma + c + e, a); atomicAdd(dbeta + c + e, bb);
+                }
+            }
         }
     }
 }
@@ -290,28 +339,30 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const unsigned sh
 
 extern "C" {
 
-int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, void* stream) {
+int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, float* colsum,
+                       void* stream) {
     OCC_CHECK_ARG(src && dst && rows >= 1 && cols >= 1 && ld_src >= cols && ld_dst >= rows, "occ_transpose_bf16: bad argument");
     OCC_CHECK_ARG(src_dtype == OCC_F32 || src_dtype == OCC_BF16, "occ_transpose_bf16: source must be f32 or bf16");
     const dim3 grid((unsigned)occ_cdiv(cols, 64), (unsigned)occ_cdiv(rows, 64)), block(256);
     OCC_CHECK_ARG(grid.y < 65536, "occ_transpose_bf16: too many rows");
     hipStream_t s = (hipStream_t)stream;
-    if (src_dtype == OCC_F32) hipLaunchKernelGGL(transpose_bf16_kernel<float>, grid, block, 0, s, (const float*)src, (unsigned short*)dst, (long long)rows, (long long)cols, (long long)ld_src, (long long)ld_dst);
-    else hipLaunchKernelGGL(transpose_bf16_kernel<unsigned short>, grid, block, 0, s, (const unsigned short*)src, (unsigned short*)dst, (long long)rows, (long long)cols, (long long)ld_src, (long long)ld_dst);
+    if (src_dtype == OCC_F32) hipLaunchKernelGGL(transpose_bf16_kernel<float>, grid, block, 0, s, (const float*)src, (unsigned short*)dst, (long long)rows, (long long)cols, (long long)ld_src, (long long)ld_dst, colsum);
+    else hipLaunchKernelGGL(transpose_bf16_kernel<unsigned short>, grid, block, 0, s, (const unsigned short*)src, (unsigned short*)dst, (long long)rows, (long long)cols, (long long)ld_src, (long long)ld_dst, colsum);
     OCC_LAUNCH_CHECK("occ_transpose_bf16");
     return OCC_OK;
 }
 
-int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, float* dgamma, float* dbeta,
-                      int64_t rows, int64_t C, float eps, void* stream) {
+int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
+                      float* dbeta, int64_t rows, int64_t C, float eps, void* stream) {
     OCC_CHECK_ARG(dy && x && gamma && dx && dgamma && dbeta, "occ_layernorm_bwd: null pointer");
     OCC_CHECK_ARG(rows >= 1 && C >= 8 && C % 8 == 0 && C <= 2048, "occ_layernorm_bwd: C must be a multiple of 8 in [8,2048]");
     OCC_CHECK_ARG(dy_dtype == OCC_F32 || dy_dtype == OCC_BF16, "occ_layernorm_bwd: dy must be f32 or bf16");
-    long long blocks = occ_cdiv(rows, 4);
-    if (blocks > 512) blocks = 512;
+    long long blocks = occ_cdiv(rows, 4 * 8);           // >= 8 rows per wave so the per-workgroup atomics amortise
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
     const int nit = (int)((C + 511) / 512);
     hipStream_t s = (hipStream_t)stream;
-#define OCC_LNB(T, N) hipLaunchKernelGGL((layernorm_bwd_kernel<T, N>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)dy, x, gamma, dres, dx, dgamma, dbeta, (long long)rows, (int)C, eps)
+#define OCC_LNB(T, N) hipLaunchKernelGGL((layernorm_bwd_kernel<T, N>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)dy, x, gamma, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, (long long)rows, (int)C, eps)
     if (dy_dtype == OCC_F32) { if (nit == 1) OCC_LNB(float, 1); else if (nit == 2) OCC_LNB(float, 2); else if (nit == 3) OCC_LNB(float, 3); else OCC_LNB(float, 4); }
     else { if (nit == 1) OCC_LNB(unsigned short, 1); else if (nit == 2) OCC_LNB(unsigned short, 2); else if (nit == 3) OCC_LNB(unsigned short, 3); else OCC_LNB(unsigned short, 4); }
 #undef OCC_LNB

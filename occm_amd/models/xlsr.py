@@ -386,6 +386,7 @@ class XlsrFineTuner(XlsrFrontend):
             tr["tA_F"], tr["tB_F"] = z(Fd, Mp), z(Fd, Mp)
             tr["tA_3D"] = z(3 * D, Mp)
             tr["dx"] = e(M, D, dt=f32)
+            tr["dxb"] = e(M, D)                                   # bf16 copy of the residual-stream gradient (GEMM operand)
             tr["du"], tr["dh"], tr["da"], tr["dqkv"] = e(M, Fd), e(M, D), e(M, D), e(M, 3 * D)
             ws["tr"] = tr
         return ws
@@ -455,12 +456,10 @@ class XlsrFineTuner(XlsrFrontend):
 
     def _wgrad(self, dy, x, N, Kd, M, Mp, tA, tB, gname, bias_name):
         """G[gname] [N,Kd] += dy^T x ; G[bias] += colsum(dy).  dy [M,N], x [M,Kd] (f32 or bf16)."""
-        from .. import backend_ops as K
-        ops.transpose_bf16(dy, tA, M, N, ld_src=N, ld_dst=Mp)
+        ops.transpose_bf16(dy, tA, M, N, ld_src=N, ld_dst=Mp, colsum=self.mg[bias_name])      # bias gradient rides along
         ops.transpose_bf16(x, tB, M, Kd, ld_src=Kd, ld_dst=Mp)
         g = self.mg[gname]
         ops.gemm_raw(N, Kd, Mp, tA, rowmap(N, 0, Mp), tB, Mp, g, rowmap(N, 0, Kd), OCC_F32, OCC_BF16_CODE, R=g, r_map=rowmap(N, 0, Kd), r_dtype=OCC_F32)
-        K.colsum(dy, rowmap(M, 0, N), M, N, self.mg[bias_name])
 
     def backward(self, dfeats):
         """dfeats f32 [B,T,dim] (gradient wrt the returned features) -> accumulates into self.G."""
@@ -473,21 +472,21 @@ class XlsrFineTuner(XlsrFrontend):
         T, M, D, Fd, Mp = ws["T"], ws["M"], cfg.dim, cfg.ffn, tr["Mp"]
         bfc, hd = OCC_BF16_CODE, D // cfg.heads
         xmap, fmap, qmap = rowmap(M, 0, D), rowmap(M, 0, Fd), rowmap(M, 0, 3 * D)
-        dx = tr["dx"]
-        ops.layernorm_bwd(dfeats.contiguous().view(M, D), tr["x_out"], w["enc_ln.g"], None, dx, self.mg["enc_ln.g"], self.mg["enc_ln.b"])
+        dx, dxb = tr["dx"], tr["dxb"]
+        ops.layernorm_bwd(dfeats.contiguous().view(M, D), tr["x_out"], w["enc_ln.g"], None, dx, self.mg["enc_ln.g"], self.mg["enc_ln.b"], dx_bf16=dxb)
         for i in range(cfg.layers - 1, -1, -1):
             s = tr["layers"][i]
             # ---- FFN: x3 = x_mid + fc2(gelu(fc1(LN2(x_mid))))
             self._wgrad(dx, s["f"], D, Fd, M, Mp, tr["tA_D"], tr["tB_F"], "l%d.fc2.w" % i, "l%d.fc2.b" % i)
-            ops.gemm_raw(M, Fd, D, dx, xmap, self.wT["l%d.fc2.w" % i], D, tr["du"], fmap, bfc, OCC_AF32_WBF16, act=ACT_GELU_GRAD, aux=s["u"])
+            ops.gemm_raw(M, Fd, D, dxb, xmap, self.wT["l%d.fc2.w" % i], D, tr["du"], fmap, bfc, bfc, act=ACT_GELU_GRAD, aux=s["u"])
             self._wgrad(tr["du"], s["h2"], Fd, D, M, Mp, tr["tA_F"], tr["tB_D"], "l%d.fc1.w" % i, "l%d.fc1.b" % i)
             ops.gemm_raw(M, D, Fd, tr["du"], fmap, self.wT["l%d.fc1.w" % i], Fd, tr["dh"], xmap, bfc, bfc)
-            ops.layernorm_bwd(tr["dh"], s["x_mid"], w["l%d.ln2.g" % i], dx, dx, self.mg["l%d.ln2.g" % i], self.mg["l%d.ln2.b" % i])
+            ops.layernorm_bwd(tr["dh"], s["x_mid"], w["l%d.ln2.g" % i], dx, dx, self.mg["l%d.ln2.g" % i], self.mg["l%d.ln2.b" % i], dx_bf16=dxb)
             # ---- attention: x_mid = x_in + out_proj(attn(qkv(LN1(x_in))))
             self._wgrad(dx, s["att"], D, D, M, Mp, tr["tA_D"], tr["tB_D"], "l%d.o.w" % i, "l%d.o.b" % i)
-            ops.gemm_raw(M, D, D, dx, xmap, self.wT["l%d.o.w" % i], D, tr["da"], xmap, bfc, OCC_AF32_WBF16)
+            ops.gemm_raw(M, D, D, dxb, xmap, self.wT["l%d.o.w" % i], D, tr["da"], xmap, bfc, bfc)
             ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
             self._wgrad(tr["dqkv"], s["h1"], 3 * D, D, M, Mp, tr["tA_3D"], tr["tB_D"], "l%d.qkv.w" % i, "l%d.qkv.b" % i)
             ops.gemm_raw(M, D, 3 * D, tr["dqkv"], qmap, self.wT["l%d.qkv.w" % i], 3 * D, tr["dh"], xmap, bfc, bfc)
-            ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i])
+            ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i], dx_bf16=dxb)
         self.ctx = None

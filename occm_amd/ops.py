@@ -123,18 +123,19 @@ def attention_bwd(qkv, o, dout, lse, B, T, H, hd, scale, dqkv=None):
     return dqkv
 
 
-def transpose_bf16(src, dst, rows, cols, ld_src=None, ld_dst=None):
-    """dst[c, r] = bf16(src[r, c]); dst is a bf16 [cols, ld_dst] buffer whose pad columns the caller keeps at zero."""
+def transpose_bf16(src, dst, rows, cols, ld_src=None, ld_dst=None, colsum=None):
+    """dst[c, r] = bf16(src[r, c]); dst is a bf16 [cols, ld_dst] buffer whose pad columns the caller keeps at zero.
+    colsum (optional f32 [cols]) accumulates the column sums of src (bias gradient)."""
     check(lib().occ_transpose_bf16(ptr(src), dtype_code(src), ptr(dst), int(rows), int(cols), int(ld_src or cols), int(ld_dst or dst.shape[-1]),
-                                   stream_ptr()), "occ_transpose_bf16")
+                                   ptr(colsum), stream_ptr()), "occ_transpose_bf16")
     return dst
 
 
-def layernorm_bwd(dy, x, gamma, dres, dx, dgamma, dbeta, eps=1e-5):
+def layernorm_bwd(dy, x, gamma, dres, dx, dgamma, dbeta, eps=1e-5, dx_bf16=None):
     C = x.shape[-1]
     rows = x.numel() // C
-    check(lib().occ_layernorm_bwd(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(dres), ptr(dx), ptr(dgamma), ptr(dbeta), rows, C, float(eps),
-                                  stream_ptr()), "occ_layernorm_bwd")
+    check(lib().occ_layernorm_bwd(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(dgamma), ptr(dbeta), rows, C,
+                                  float(eps), stream_ptr()), "occ_layernorm_bwd")
     return dx
 
 

@@ -25,8 +25,10 @@ def test_transpose_bf16(rows, cols, dt):
     x = _r(rows, cols, seed=1).to(dt)
     ld = (rows + 63) // 64 * 64
     dst = torch.zeros(cols, ld, dtype=torch.bfloat16, device="cuda")
-    ops.transpose_bf16(x.cuda(), dst, rows, cols)
+    cs = torch.zeros(cols, device="cuda")
+    ops.transpose_bf16(x.cuda(), dst, rows, cols, colsum=cs)
     torch.testing.assert_close(dst[:, :rows].cpu().float(), x.bfloat16().float().T)
+    torch.testing.assert_close(cs.cpu(), x.float().sum(0), rtol=1e-4, atol=1e-3)
     assert float(dst[:, rows:].abs().max()) == 0.0 if ld > rows else True
 
 
@@ -45,8 +47,9 @@ def test_layernorm_bwd(C):
     torch.testing.assert_close(dg.cpu(), g.grad, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3)
     dyb = dy.bfloat16()
-    dx2 = torch.empty(rows, C, device="cuda")
-    ops.layernorm_bwd(dyb.cuda(), x.detach().cuda(), g.detach().cuda(), None, dx2, dg, db)
+    dx2, dxb = torch.empty(rows, C, device="cuda"), torch.empty(rows, C, device="cuda", dtype=torch.bfloat16)
+    ops.layernorm_bwd(dyb.cuda(), x.detach().cuda(), g.detach().cuda(), None, dx2, dg, db, dx_bf16=dxb)
+    torch.testing.assert_close(dxb.float(), dx2.bfloat16().float())
     x.grad = None
     F.layer_norm(x, (C,), g, b).backward(dyb.float())
     torch.testing.assert_close(dx2.cpu(), x.grad, rtol=1e-4, atol=1e-4)
