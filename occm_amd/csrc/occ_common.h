@@ -106,8 +106,10 @@ static inline int64_t occ_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 struct RowMapI { long long rpb, bstride, rstride, rpl, lstride; };
 static inline RowMapI to_rowmap(const occ_rowmap& m) { return RowMapI{m.rows_per_batch, m.batch_stride, m.row_stride, m.rows_per_line, m.line_stride}; }
 __device__ __forceinline__ long long row_off(const RowMapI& m, long long row) {
-    const long long b = row / m.rpb;
-    const long long r = row - b * m.rpb;
-    if (m.rpl > 0) { const long long l = r / m.rpl; return b * m.bstride + l * m.lstride + (r - l * m.rpl) * m.rstride; }
-    return b * m.bstride + r * m.rstride;
+    if (row < m.rpb && m.rpl == 0) return row * m.rstride;              // plain matrix: no division at all
+    // rows and rows_per_batch fit 32 bits everywhere on this path: unsigned 32-bit division is ~4x cheaper than 64-bit
+    const unsigned rw = (unsigned)row, rpb = (unsigned)m.rpb;
+    const unsigned b = rw / rpb, r = rw - b * rpb;
+    if (m.rpl > 0) { const unsigned rpl = (unsigned)m.rpl, l = r / rpl; return b * m.bstride + l * m.lstride + (long long)(r - l * rpl) * m.rstride; }
+    return b * m.bstride + (long long)r * m.rstride;
 }
