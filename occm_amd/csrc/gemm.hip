@@ -34,6 +34,7 @@ struct GemmArgs {
     int act; float alpha;
     unsigned short* aux;
     int nbm, nbn;
+    int group_m;              // >0: walk GROUP_M m-tiles per n-tile before moving on (L2-sized working set), 0: n fastest
     long long a_gstride, w_gstride, c_gstride;
 };
 
@@ -47,18 +48,19 @@ __device__ __forceinline__ float act_rt(int act, float v) {
     }
 }
 
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][4], long long m0, long long n0, int wm, int wn, int fr, int fq,
-                                              long long cshift) {
-    // ---- epilogue: lane owns C[m][n..n+3]
+// acc[i][j]: i = 16-column block of the wave's 64 output columns, j = 16-row block of its NJ*16 output rows;
+// mrow0 / ncol0 = first row / column of the wave's sub-tile.  A lane owns C[m][n..n+3].
+template <int NJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long long m = m0 + wm * 64 + j * 16 + fr;
+    for (int j = 0; j < NJ; ++j) {
+        const long long m = mrow0 + j * 16 + fr;
         if (m >= a.M) continue;
         const long long coff = row_off(a.cmap, m) + cshift;
         const long long roff = a.R ? row_off(a.rmap, m) + cshift : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long long n = n0 + wn * 64 + i * 16 + fq * 4;
+            const long long n = ncol0 + i * 16 + fq * 4;
             if (n >= a.N) continue;
             float v[4];
 #pragma unroll
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
-    gemm_epilogue(a, acc, m0, n0, wm, wn, fr, fq, cshift);
+    gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -260,7 +262,15 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
     const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    if (a.group_m > 0) {                       // grouped order: GROUP_M m-tiles share each W panel while their X panels stay in L2
+        const int per_group = a.group_m * a.nbn;
+        const int gid = vid / per_group, first_m = gid * a.group_m;
+        const int gsz = a.nbm - first_m < a.group_m ? a.nbm - first_m : a.group_m;
+        const int loc = vid - gid * per_group;
+        tile_m = first_m + loc % gsz;
+        tile_n = loc / gsz;
+    }
     const long long m0 = (long long)tile_m * TMT, n0 = (long long)tile_n * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = TMT == 128 ? (wave & 1) : (wave & 3), wn = TMT == 128 ? (wave >> 1) : (wave >> 2);
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
         }
         __syncthreads();
     }
-    gemm_epilogue(a, acc, m0, n0, wm, wn, fr, fq, cshift);
+    gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
 }
 
 __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_dma2_kernel(const GemmArgs a) {
@@ -404,7 +414,217 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_dma2_kernel(const GemmAr
                         *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
         }
     }
-    gemm_epilogue(a, acc, m0, n0, wm, wn, fr, fq, cshift);
+    gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined bf16 kernel for the big front-end GEMMs: ONE workgroup per CU (8 waves), block tile (WGM*NJ*16) x (WGN*64),
+// two LDS stages filled by LDS-DMA; the DMA of slab s+1 is issued right after the barrier that publishes slab s and flies
+// under the MFMAs of slab s, one barrier per slab.  256x128 (WGM=4, WGN=2, NJ=4) moves one L2 byte per 85 FLOP and
+// 256x256 (WGM=2, WGN=4, NJ=8; 128x64 per wave) one per 128 FLOP -- the 128x128 tile's 64 FLOP/B is what caps it near
+// 0.9 PFLOP/s (a CU pulls ~55-64 B/clk from L2, its MFMA rate needs 64 B/clk at that intensity).
+template <int WGM, int WGN, int NJ>
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_bf16_pipe_kernel(const GemmArgs a) {
+    constexpr int ES = 2, CE = 8, SLAB_K = 64;
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int TMB = WGM * NJ * 16, TNB = WGN * 64;
+    constexpr int RPP = NT / 8;                      // rows staged per pass (64 for 512 threads)
+    constexpr int XP = TMB / RPP, WP = TNB / RPP;
+    constexpr int STAGE = (TMB + TNB) * CHUNKS;      // uint4 per stage
+    extern __shared__ uint4 plds[];                  // [2][X rows | W rows][8 positions]
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    const long long m0 = (long long)tile_m * TMB, n0 = (long long)tile_n * TNB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WGM, wn = wave / WGM;
+    const long long grp = blockIdx.y;
+    const char* Xg = a.X + grp * a.a_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const long long cshift = grp * a.c_gstride;
+
+    const int pos = tid & 7, srow = tid >> 3;
+    const char* xsrc[XP]; const char* wsrc[WP];
+    int xc[XP], wc[WP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int row = srow + RPP * i;
+        long long m = m0 + row; if (m > a.M - 1) m = a.M - 1;
+        xsrc[i] = Xg + row_off(a.xmap, m) * ES;
+        xc[i] = pos ^ (row & 7);
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int row = srow + RPP * i;
+        long long n = n0 + row; if (n > a.N - 1) n = a.N - 1;
+        wsrc[i] = Wg + n * a.ldw * ES;
+        wc[i] = pos ^ (row & 7);
+    }
+    const int nslab = (int)(a.K / SLAB_K);
+    auto stage = [&](int slab, int buf) {
+        uint4* sx = plds + buf * STAGE;
+        uint4* sw = sx + TMB * CHUNKS;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const long long k0 = (long long)slab * SLAB_K + xc[i] * CE;
+            long long kx = k0;
+            if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx * ES), (lds_void*)&sx[(wave * 8 + RPP * i) * CHUNKS], 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            const long long k0 = (long long)slab * SLAB_K + wc[i] * CE;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + k0 * ES), (lds_void*)&sw[(wave * 8 + RPP * i) * CHUNKS], 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    stage(0, 0);
+    for (int slab = 0; slab < nslab; ++slab) {
+        const int cur = slab & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of slab `slab` have landed
+        __syncthreads();                                       // everyone's have; stage cur^1 is no longer being read
+        if (slab + 1 < nslab) stage(slab + 1, cur ^ 1);
+        const uint4* sx = plds + cur * STAGE;
+        const uint4* sw = sx + TMB * CHUNKS;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 wf[4], xf[NJ];
+            const int chk = kb * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = wn * 64 + i * 16 + fr;
+                wf[i] = sw[rw * CHUNKS + (chk ^ (rw & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int rx = wm * (NJ * 16) + j * 16 + fr;
+                xf[j] = sx[rx * CHUNKS + (chk ^ (rx & 7))];
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    gemm_epilogue<NJ>(a, acc, m0 + wm * (NJ * 16), n0 + wn * 64, fr, fq, cshift);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Producer / consumer variant: 256x128 block tile, 8 consumer waves (4x2, 64x64 each) that ONLY read LDS and issue MFMAs,
+// plus 4 loader waves (one per SIMD) that ONLY issue the LDS-DMA of the next slab.  An LDS-DMA instruction costs its wave
+// 60-180 issue cycles (MI355X_MICROARCH.md, cycle constants); taking the 12 per slab out of the MFMA waves' in-order streams
+// is what the deep-pipelined templates achieve by hand interleaving.  Two LDS stages, one barrier per slab.
+__global__ __launch_bounds__(768, 3) void gemm_bf16_pc_kernel(const GemmArgs a) {
+    constexpr int ES = 2, CE = 8, SLAB_K = 64;
+    constexpr int TMB = 256, TNB = 128;
+    constexpr int STAGE = (TMB + TNB) * CHUNKS;
+    extern __shared__ uint4 plds[];
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    const long long m0 = (long long)tile_m * TMB, n0 = (long long)tile_n * TNB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long grp = blockIdx.y;
+    const char* Xg = a.X + grp * a.a_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const long long cshift = grp * a.c_gstride;
+    const int nslab = (int)(a.K / SLAB_K);
+
+    if (wave >= 8) {
+        // ---------------- loader waves: 48 one-KiB pieces per slab, 12 per wave ----------------
+        const int lw = wave - 8;
+        const char* src[12]; int chunk[12]; int dstoff[12]; bool isx[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int blk = lw * 12 + i;                       // 0..31: X row blocks, 32..47: W row blocks (8 rows each)
+            isx[i] = blk < 32;
+            const int row = (isx[i] ? blk : blk - 32) * 8 + (lane >> 3);
+            chunk[i] = (lane & 7) ^ (row & 7);
+            if (isx[i]) {
+                long long m = m0 + row; if (m > a.M - 1) m = a.M - 1;
+                src[i] = Xg + row_off(a.xmap, m) * ES;
+                dstoff[i] = (blk * 8) * CHUNKS;
+            } else {
+                long long n = n0 + row; if (n > a.N - 1) n = a.N - 1;
+                src[i] = Wg + n * a.ldw * ES;
+                dstoff[i] = (TMB + (blk - 32) * 8) * CHUNKS;
+            }
+        }
+        auto stage = [&](int slab, int buf) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const long long k0 = (long long)slab * SLAB_K + chunk[i] * CE;
+                long long kk = k0;
+                if (isx[i] && a.nseg > 1) { const long long sg = k0 / a.seg_len; kk = sg * a.seg_stride + (k0 - sg * a.seg_len); }
+                __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + kk * ES), (lds_void*)&plds[buf * STAGE + dstoff[i]], 16, 0, 0);
+            }
+        };
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int slab = 0; slab < nslab; ++slab) {
+            if (slab + 1 < nslab) { stage(slab + 1, (slab + 1) & 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            __syncthreads();
+        }
+        return;
+    }
+    // ---------------- consumer waves ----------------
+    const int wm = wave & 3, wn = wave >> 2;
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int slab = 0; slab < nslab; ++slab) {
+        const uint4* sx = plds + (slab & 1) * STAGE;
+        const uint4* sw = sx + TMB * CHUNKS;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 wf[4], xf[4];
+            const int chk = kb * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = wn * 64 + i * 16 + fr;
+                wf[i] = sw[rw * CHUNKS + (chk ^ (rw & 7))];
+                const int rx = wm * 64 + i * 16 + fr;
+                xf[i] = sx[rx * CHUNKS + (chk ^ (rx & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+}
+
+template <int WGM, int WGN, int NJ>
+int launch_pipe(GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_t s) {
+    constexpr int TMB = WGM * NJ * 16, TNB = WGN * 64;
+    a.nbm = (int)occ_cdiv(d->M, TMB); a.nbn = (int)occ_cdiv(d->N, TNB);
+    const size_t shm = (size_t)2 * (TMB + TNB) * CHUNKS * sizeof(uint4);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<WGM, WGN, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) { occ_set_error("occ_gemm: cannot raise the LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<WGM, WGN, NJ>), dim3((unsigned)((long long)a.nbm * a.nbn), (unsigned)ng), dim3(WGM * WGN * 64), shm, s, a);
+    return OCC_OK;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -445,6 +665,9 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     a.C = (char*)d->C; a.cmap = to_rowmap(d->c_map); a.c_dtype = d->c_dtype;
     a.act = d->act; a.alpha = d->alpha; a.aux = (unsigned short*)d->aux;
     a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
+    // grouped tile order (8 m-tiles per W panel) measured +3 % on the N >= 3072 front-end GEMMs and +10 % at 4096^3, -2 % at N = 1024
+    static const int group_m_env = getenv("OCC_GEMM_GROUP_M") ? atoi(getenv("OCC_GEMM_GROUP_M")) : -1;
+    a.group_m = group_m_env >= 0 ? group_m_env : (a.nbn >= 16 ? 8 : 0);
     const long long ng = d->n_groups > 1 ? d->n_groups : 1;
     a.a_gstride = ng > 1 ? d->a_group_stride : 0; a.w_gstride = ng > 1 ? d->w_group_stride : 0; a.c_gstride = ng > 1 ? d->c_group_stride : 0;
     OCC_CHECK_ARG(ng < 65536 && a.a_gstride % ce == 0 && a.w_gstride % ce == 0 && a.c_gstride % 4 == 0, "occ_gemm: bad group strides");
@@ -456,7 +679,16 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     // 256x128 tiles only pay on large square problems (4096^3: 999 vs 865 TFLOP/s); on the front-end shapes (M = 6368, or N = 512)
     // the 128x128 tile's finer granularity wins by 3-15 % (scripts/bench_gemm.py), so it stays the default there.
     const bool big = d->M >= 4096 && d->N >= 4096 && d->M % 256 == 0;
-    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 3 || (variant == 1 && big))) {
+    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 7) {
+        a.nbm = (int)occ_cdiv(d->M, 256); a.nbn = (int)occ_cdiv(d->N, 128);
+        const size_t shm = (size_t)2 * (256 + 128) * CHUNKS * sizeof(uint4);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) { occ_set_error("occ_gemm: cannot raise the LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+        hipLaunchKernelGGL(gemm_bf16_pc_kernel, dim3((unsigned)((long long)a.nbm * a.nbn), (unsigned)ng), dim3(768), shm, s, a);
+    } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 5 || variant == 6)) {
+        const int rc = variant == 5 ? launch_pipe<4, 2, 4>(a, d, ng, s) : launch_pipe<2, 4, 8>(a, d, ng, s);
+        if (rc != OCC_OK) return rc;
+    } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 3 || (variant == 1 && big))) {
         a.nbm = (int)nbm256;
         hipLaunchKernelGGL(gemm_bf16_dma_kernel<256>, dim3((unsigned)(nbm256 * a.nbn), (unsigned)ng), dim3(512), 0, s, a);
     } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 1 || variant == 4))
