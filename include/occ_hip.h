@@ -127,6 +127,7 @@ typedef struct occ_gemm_tn_desc {
     void* C; int64_t ldc;
     float alpha;
     void* colsum;                      /* optional f32 [N1]: += alpha * column sums of A (the bias gradient), or NULL */
+    int a_dtype, b_dtype;              /* OCC_F32 (0, default) or OCC_BF16: operand storage; products and sums are f32 either way */
 } occ_gemm_tn_desc;
 int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream);
 /* out[n] += alpha * sum_m A[m,n] (bias gradients).                                                   */
@@ -250,6 +251,26 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
 int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
                        float* colsum, void* stream);
 /* dx = LayerNorm'(x)^T dy (+ dres, the residual-branch gradient; dx may alias dres); dgamma += sum dy*xhat; dbeta += sum dy. */
+/* Same with the source rows addressed through a row map (strided conv windows, interiors of padded buffers).               */
+int occ_transpose_bf16_rows(const void* src, int src_dtype, const occ_rowmap* src_map, void* dst, int64_t rows, int64_t cols,
+                            int64_t ld_dst, float* colsum, void* stream);
+/* General form: x f32 or bf16; gelu != 0 treats dy as the gradient wrt gelu(LN(x)) (conv blocks of the feature extractor, needs
+ * beta); dx (f32, contiguous) and dx_bf16 (through dx_bf16_map, NULL = contiguous) are each optional.                      */
+int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
+                         const float* dres, float* dx, void* dx_bf16, const occ_rowmap* dx_bf16_map, float* dgamma, float* dbeta,
+                         int64_t rows, int64_t C, float eps, int gelu, void* stream);
+/* out (bf16, through out_map) = dy (f32 [rows,C]) * gelu'(u (bf16 [rows,C])): gradient through the positional conv's GELU.   */
+int occ_gelu_bwd_rows(const float* dy, const void* u, void* out, const occ_rowmap* out_map, int64_t rows, int64_t C, void* stream);
+/* Backward of occ_conv0_ln_gelu (recomputes the block from the waveform): dw [C,k], dbias, dgamma, dbeta accumulated.       */
+int occ_conv0_ln_gelu_bwd(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta, const void* dact,
+                          int dact_dtype, float* dw, float* dbias, float* dgamma, float* dbeta, int64_t B, int64_t L, int64_t Tout,
+                          int64_t C, int64_t k, int64_t stride, float eps, void* stream);
+/* weight_norm(dim=2) of fairseq's pos_conv: v f32 [O,I,K], g f32 [K] -> bf16 GEMM operands w_fwd [G][O/G][K][I] and (optional)
+ * w_bwd [G][I][K][O/G] (taps reversed, for the input gradient), norms f32 [K]; bwd maps a packed-layout weight gradient to dv, dg. */
+int occ_weight_norm_pack(const float* v, const float* g, void* w_fwd, void* w_bwd, float* norms, int64_t O, int64_t I, int64_t K,
+                         int64_t G, void* stream);
+int occ_weight_norm_bwd(const float* v, const float* g, const float* norms, const float* dw_packed, float* dv, float* dg, int64_t O,
+                        int64_t I, int64_t K, int64_t G, void* stream);
 /* dx_bf16 (optional): a bf16 copy of dx for the next input-gradient GEMMs.                                             */
 int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16,
                       float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, void* stream);

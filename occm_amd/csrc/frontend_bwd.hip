@@ -13,7 +13,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 // dst[c][r] = bf16(src[r][c]); dst rows have ld_dst >= rows elements (pad columns are left untouched: callers keep them 0).
 template <typename TS>
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const TS* __restrict__ src, unsigned short* __restrict__ dst, long long rows, long long cols,
-                                                            long long ld_src, long long ld_dst, float* __restrict__ colsum) {
+                                                            RowMapI smap, long long ld_dst, float* __restrict__ colsum) {
     __shared__ unsigned short tile[64][66];
     __shared__ float csum[4][64];
     float cs = 0.f;
@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const TS* __restric
         const long long r = r0 + ty + 4 * i, c = c0 + tx;
         unsigned short v = 0;
         if (r < rows && c < cols) {
-            if (sizeof(TS) == 4) { const float f = reinterpret_cast<const float*>(src)[r * ld_src + c]; cs += f; v = f32_to_bf16_bits(f); }
-            else { v = reinterpret_cast<const unsigned short*>(src)[r * ld_src + c]; cs += bf16_bits_to_f32(v); }
+            const long long so = row_off(smap, r) + c;
+            if (sizeof(TS) == 4) { const float f = reinterpret_cast<const float*>(src)[so]; cs += f; v = f32_to_bf16_bits(f); }
+            else { v = reinterpret_cast<const unsigned short*>(src)[so]; cs += bf16_bits_to_f32(v); }
         }
         tile[ty + 4 * i][tx] = v;
     }
@@ -58,20 +59,23 @@ template <> struct LVec8<unsigned short> {
     }
 };
 
-template <typename TDY, int NIT>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
-                                                           const float* __restrict__ dres, float* __restrict__ dx, unsigned short* __restrict__ dx_bf16,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, long long rows, int C, float eps) {
+// GELU: dy is the gradient wrt gelu(LN(x)) (the conv blocks of the feature extractor); the kernel rebuilds z = LN(x) and
+// multiplies dy by gelu'(z) first.  dx (f32, contiguous) and dx_bf16 (through a row map) are both optional outputs.
+template <typename TDY, typename TX, int NIT, bool GELU>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ dres, float* __restrict__ dx,
+                                                           unsigned short* __restrict__ dx_bf16, RowMapI bmap, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, long long rows, int C, float eps) {
     __shared__ float red[3][2][NIT * 512];           // waves 1..3 park their partial dgamma / dbeta here
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long wave0 = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
-    float dg[NIT][8], db[NIT][8], g[NIT][8];
+    float dg[NIT][8], db[NIT][8], g[NIT][8], bt[NIT][8];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int c = (it * 64 + lane) * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; g[it][e] = 0.f; }
-        if (c < C) LVec8<float>::load(gamma + c, g[it]);
+        for (int e = 0; e < 8; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; g[it][e] = 0.f; bt[it][e] = 0.f; }
+        if (c < C) { LVec8<float>::load(gamma + c, g[it]); if (GELU) LVec8<float>::load(beta + c, bt[it]); }
     }
     for (long long row = wave0; row < rows; row += nwaves) {
         float xv[NIT][8], dv[NIT][8];
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
         for (int it = 0; it < NIT; ++it) {
             const int c = (it * 64 + lane) * 8;
             if (c < C) {
-                LVec8<float>::load(x + row * C + c, xv[it]);
+                LVec8<TX>::load(x + row * C + c, xv[it]);
                 LVec8<TDY>::load(dy + row * C + c, dv[it]);
             } else {
 #pragma unroll
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xh = (xv[it][e] - mean) * rstd;
+                if (GELU) dv[it][e] *= gelu_grad(xh * g[it][e] + bt[it][e]);
                 const float dxh = dv[it][e] * g[it][e];
                 xv[it][e] = xh;                    // keep xhat (zero-gamma padding lanes contribute nothing)
                 s1 += dxh; s2 += dxh * xh;
@@ -123,13 +128,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
                     v[e] = rstd * (dv[it][e] * g[it][e] - s1 - xv[it][e] * s2);
                     if (dres) v[e] += r[e];
                 }
-                *reinterpret_cast<float4*>(dx + row * C + c) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(dx + row * C + c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                if (dx) {
+                    *reinterpret_cast<float4*>(dx + row * C + c) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dx + row * C + c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
                 if (dx_bf16) {
                     unsigned w[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
-                    *reinterpret_cast<uint4*>(dx_bf16 + row * C + c) = make_uint4(w[0], w[1], w[2], w[3]);
+                    *reinterpret_cast<uint4*>(dx_bf16 + row_off(bmap, row) + c) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
         }
@@ -335,39 +342,223 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const unsigned sh
     }
 }
 
+
+// out[omap(r)][c] = bf16(dy[r][c] * gelu'(u[r][c]))   (gradient through the positional conv's GELU, written into the padded buffer)
+__global__ void gelu_bwd_rows_kernel(const float* __restrict__ dy, const unsigned short* __restrict__ u, unsigned short* __restrict__ out, RowMapI omap,
+                                     long long rows, int C) {
+    const long long n = rows * (C / 4);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / (C / 4); const int c = (int)(i - r * (C / 4)) * 4;
+        const float4 d = *reinterpret_cast<const float4*>(dy + r * C + c);
+        const uint2 uu = *reinterpret_cast<const uint2*>(u + r * C + c);
+        const float v0 = d.x * gelu_grad(bf16_bits_to_f32((unsigned short)(uu.x & 0xffff))), v1 = d.y * gelu_grad(bf16_bits_to_f32((unsigned short)(uu.x >> 16)));
+        const float v2 = d.z * gelu_grad(bf16_bits_to_f32((unsigned short)(uu.y & 0xffff))), v3 = d.w * gelu_grad(bf16_bits_to_f32((unsigned short)(uu.y >> 16)));
+        uint2 o;
+        o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
+        o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
+        *reinterpret_cast<uint2*>(out + row_off(omap, r) + c) = o;
+    }
+}
+
+// Backward of the fused first conv block (Conv1d(1->512,k,stride) + LayerNorm + GELU): everything is recomputed from the
+// waveform, nothing was saved.  One wave per frame, lane = 8 channels; weight / bias / LayerNorm gradients are reduced in
+// registers over the wave's frames, then over the 4 waves through LDS, then one set of atomics per workgroup.
+constexpr int C0B_FRAMES = 256, C0B_MAXK = 16;
+template <typename TD>
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, const TD* __restrict__ dact,
+                                                       float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                       int L, int Tout, int k, int stride, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float smp[];          // samples | reduction scratch [3][512*(k+3)]
+    const int b = blockIdx.y, f0 = blockIdx.x * C0B_FRAMES;
+    const int nsamp = (C0B_FRAMES - 1) * stride + k;
+    float* red = smp + ((nsamp + 3) & ~3);
+    const float* wb = wav + (size_t)b * L;
+    for (int i = threadIdx.x; i < nsamp; i += 256) { const int g = f0 * stride + i; smp[i] = g < L ? wb[g] : 0.f; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = lane * 8;
+    float wr[8][C0B_MAXK], br[8], gr[8], ber[8];
+    float gw[8][C0B_MAXK], gb[8], gg[8], gbe[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        br[e] = bias[c0 + e]; gr[e] = gamma[c0 + e]; ber[e] = beta[c0 + e];
+        gb[e] = 0.f; gg[e] = 0.f; gbe[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < C0B_MAXK; ++t) { wr[e][t] = t < k ? w[(size_t)(c0 + e) * k + t] : 0.f; gw[e][t] = 0.f; }
+    }
+    __syncthreads();
+    for (int fi = 0; fi < C0B_FRAMES / 4; ++fi) {
+        const int fl = wave * (C0B_FRAMES / 4) + fi, f = f0 + fl;
+        if (f >= Tout) break;
+        float acc[8], xs[C0B_MAXK];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = br[e];
+#pragma unroll
+        for (int t = 0; t < C0B_MAXK; ++t) {
+            xs[t] = t < k ? smp[fl * stride + t] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(wr[e][t], xs[t], acc[e]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += acc[e];
+        const float mean = wave_sum(s) * (1.0f / 512.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = acc[e] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 512.0f) + eps);
+        float dv[8];
+        LVec8<TD>::load(dact + ((size_t)b * Tout + f) * 512 + c0, dv);
+        float xh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xh[e] = (acc[e] - mean) * rstd;
+            const float dz = dv[e] * gelu_grad(xh[e] * gr[e] + ber[e]);
+            gg[e] += dz * xh[e]; gbe[e] += dz;
+            dv[e] = dz * gr[e];
+            s1 += dv[e]; s2 += dv[e] * xh[e];
+        }
+        s1 = wave_sum(s1) * (1.0f / 512.0f); s2 = wave_sum(s2) * (1.0f / 512.0f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dp = rstd * (dv[e] - s1 - xh[e] * s2);
+            gb[e] += dp;
+#pragma unroll
+            for (int t = 0; t < C0B_MAXK; ++t) gw[e][t] = fmaf(dp, xs[t], gw[e][t]);
+        }
+    }
+    // reduce over the 4 waves: layout per wave [512][k+3] = (dw[k], dbias, dgamma, dbeta)
+    const int rs = k + 3;
+    __syncthreads();
+    if (wave > 0) {
+        float* r = red + (size_t)(wave - 1) * 512 * rs;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            for (int t = 0; t < k; ++t) r[(c0 + e) * rs + t] = gw[e][t];
+            r[(c0 + e) * rs + k] = gb[e]; r[(c0 + e) * rs + k + 1] = gg[e]; r[(c0 + e) * rs + k + 2] = gbe[e];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            for (int t = 0; t < k; ++t) {
+                float v = gw[e][t];
+                for (int w2 = 0; w2 < 3; ++w2) v += red[(size_t)w2 * 512 * rs + c * rs + t];
+                atomicAdd(dw + (size_t)c * k + t, v);
+            }
+            float v0 = gb[e], v1 = gg[e], v2 = gbe[e];
+            for (int w2 = 0; w2 < 3; ++w2) { const float* r = red + (size_t)w2 * 512 * rs + c * rs; v0 += r[k]; v1 += r[k + 1]; v2 += r[k + 2]; }
+            atomicAdd(dbias + c, v0); atomicAdd(dgamma + c, v1); atomicAdd(dbeta + c, v2);
+        }
+    }
+}
+
+// weight_norm(dim=2) of the positional conv: w[o,i,k] = g[k] * v[o,i,k] / ||v[:,:,k]||.  One workgroup per tap k.
+// pack: writes the forward GEMM operand  wf[G][n][k][c]  and the input-gradient operand  wb[G][c][j][n] = w[(G,n), c, K-1-j]  (bf16).
+__global__ __launch_bounds__(256) void weight_norm_pack_kernel(const float* __restrict__ v, const float* __restrict__ g, unsigned short* __restrict__ wf,
+                                                              unsigned short* __restrict__ wb, float* __restrict__ norms, int O, int I, int K, int G) {
+    __shared__ float red[4];
+    const int k = blockIdx.x, cgn = O / G;
+    float s = 0.f;
+    for (int idx = threadIdx.x; idx < O * I; idx += 256) { const float x = v[(size_t)idx * K + k]; s += x * x; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) norms[k] = nrm;
+    const float sc = g[k] / nrm;
+    for (int idx = threadIdx.x; idx < O * I; idx += 256) {
+        const int o = idx / I, i = idx - o * I, gi = o / cgn, n = o - gi * cgn;
+        const unsigned short val = f32_to_bf16_bits(v[(size_t)idx * K + k] * sc);
+        wf[(((size_t)gi * cgn + n) * K + k) * I + i] = val;
+        if (wb) wb[(((size_t)gi * I + i) * K + (K - 1 - k)) * cgn + n] = val;
+    }
+}
+// bwd: dWp[G][n][k][c] (f32, GEMM layout) -> dg[k] += sum dW*v/||v_k|| ; dv[o,i,k] += g/||v|| * (dW - v * sum(dW*v)/||v||^2)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ norms,
+                                                             const float* __restrict__ dwp, float* __restrict__ dv, float* __restrict__ dg, int O, int I,
+                                                             int K, int G) {
+    __shared__ float red[4];
+    const int k = blockIdx.x, cgn = O / G;
+    float s = 0.f;
+    for (int idx = threadIdx.x; idx < O * I; idx += 256) {
+        const int o = idx / I, i = idx - o * I, gi = o / cgn, n = o - gi * cgn;
+        s += dwp[(((size_t)gi * cgn + n) * K + k) * I + i] * v[(size_t)idx * K + k];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float dot = red[0] + red[1] + red[2] + red[3];
+    const float nrm = norms[k], gk = g[k];
+    if (threadIdx.x == 0) dg[k] += dot / nrm;
+    for (int idx = threadIdx.x; idx < O * I; idx += 256) {
+        const int o = idx / I, i = idx - o * I, gi = o / cgn, n = o - gi * cgn;
+        const float d = dwp[(((size_t)gi * cgn + n) * K + k) * I + i];
+        dv[(size_t)idx * K + k] += gk / nrm * (d - v[(size_t)idx * K + k] * dot / (nrm * nrm));
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, float* colsum,
-                       void* stream) {
-    OCC_CHECK_ARG(src && dst && rows >= 1 && cols >= 1 && ld_src >= cols && ld_dst >= rows, "occ_transpose_bf16: bad argument");
+int occ_transpose_bf16_rows(const void* src, int src_dtype, const occ_rowmap* src_map, void* dst, int64_t rows, int64_t cols, int64_t ld_dst,
+                            float* colsum, void* stream) {
+    OCC_CHECK_ARG(src && dst && src_map && rows >= 1 && cols >= 1 && ld_dst >= rows && src_map->rows_per_batch >= 1, "occ_transpose_bf16: bad argument");
     OCC_CHECK_ARG(src_dtype == OCC_F32 || src_dtype == OCC_BF16, "occ_transpose_bf16: source must be f32 or bf16");
     const dim3 grid((unsigned)occ_cdiv(cols, 64), (unsigned)occ_cdiv(rows, 64)), block(256);
     OCC_CHECK_ARG(grid.y < 65536, "occ_transpose_bf16: too many rows");
     hipStream_t s = (hipStream_t)stream;
-    if (src_dtype == OCC_F32) hipLaunchKernelGGL(transpose_bf16_kernel<float>, grid, block, 0, s, (const float*)src, (unsigned short*)dst, (long long)rows, (long long)cols, (long long)ld_src, (long long)ld_dst, colsum);
-    else hipLaunchKernelGGL(transpose_bf16_kernel<unsigned short>, grid, block, 0, s, (const unsigned short*)src, (unsigned short*)dst, (long long)rows, (long long)cols, (long long)ld_src, (long long)ld_dst, colsum);
+    const RowMapI sm = to_rowmap(*src_map);
+    if (src_dtype == OCC_F32) hipLaunchKernelGGL(transpose_bf16_kernel<float>, grid, block, 0, s, (const float*)src, (unsigned short*)dst, (long long)rows, (long long)cols, sm, (long long)ld_dst, colsum);
+    else hipLaunchKernelGGL(transpose_bf16_kernel<unsigned short>, grid, block, 0, s, (const unsigned short*)src, (unsigned short*)dst, (long long)rows, (long long)cols, sm, (long long)ld_dst, colsum);
     OCC_LAUNCH_CHECK("occ_transpose_bf16");
+    return OCC_OK;
+}
+
+int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, float* colsum,
+                       void* stream) {
+    OCC_CHECK_ARG(ld_src >= cols, "occ_transpose_bf16: ld_src < cols");
+    const occ_rowmap m{rows, 0, ld_src, 0, 0};
+    return occ_transpose_bf16_rows(src, src_dtype, &m, dst, rows, cols, ld_dst, colsum, stream);
+}
+
+int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta, const float* dres, float* dx,
+                         void* dx_bf16, const occ_rowmap* dx_bf16_map, float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, int gelu,
+                         void* stream) {
+    OCC_CHECK_ARG(dy && x && gamma && (dx || dx_bf16) && dgamma && dbeta, "occ_layernorm_bwd: null pointer");
+    OCC_CHECK_ARG(!gelu || beta, "occ_layernorm_bwd: the fused GELU needs beta");
+    OCC_CHECK_ARG(rows >= 1 && C >= 8 && C % 8 == 0 && C <= 2048, "occ_layernorm_bwd: C must be a multiple of 8 in [8,2048]");
+    OCC_CHECK_ARG((dy_dtype == OCC_F32 || dy_dtype == OCC_BF16) && (x_dtype == OCC_F32 || x_dtype == OCC_BF16), "occ_layernorm_bwd: dy / x must be f32 or bf16");
+    long long blocks = occ_cdiv(rows, 4 * 8);           // >= 8 rows per wave so the per-workgroup atomics amortise
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    const int nit = (int)((C + 511) / 512);
+    OCC_CHECK_ARG(nit <= 2 || !gelu, "occ_layernorm_bwd: fused GELU supports C <= 1024");
+    hipStream_t s = (hipStream_t)stream;
+    RowMapI bm{rows, 0, C, 0, 0};
+    if (dx_bf16_map) { OCC_CHECK_ARG(dx_bf16_map->rows_per_batch >= 1 && dx_bf16_map->row_stride % 8 == 0 && dx_bf16_map->batch_stride % 8 == 0, "occ_layernorm_bwd: bad bf16 row map"); bm = to_rowmap(*dx_bf16_map); }
+#define OCC_LNB(TD, TXX, N, G) hipLaunchKernelGGL((layernorm_bwd_kernel<TD, TXX, N, G>), dim3((unsigned)blocks), dim3(256), 0, s, (const TD*)dy, (const TXX*)x, gamma, beta, dres, dx, (unsigned short*)dx_bf16, bm, dgamma, dbeta, (long long)rows, (int)C, eps)
+#define OCC_LNB_N(TD, TXX, G) do { if (nit == 1) OCC_LNB(TD, TXX, 1, G); else if (nit == 2) OCC_LNB(TD, TXX, 2, G); else if (nit == 3) OCC_LNB(TD, TXX, 3, false); else OCC_LNB(TD, TXX, 4, false); } while (0)
+    const bool df = dy_dtype == OCC_F32, xf = x_dtype == OCC_F32;
+    if (gelu) {
+        if (df && xf) OCC_LNB_N(float, float, true); else if (df) OCC_LNB_N(float, unsigned short, true);
+        else if (xf) OCC_LNB_N(unsigned short, float, true); else OCC_LNB_N(unsigned short, unsigned short, true);
+    } else {
+        if (df && xf) OCC_LNB_N(float, float, false); else if (df) OCC_LNB_N(float, unsigned short, false);
+        else if (xf) OCC_LNB_N(unsigned short, float, false); else OCC_LNB_N(unsigned short, unsigned short, false);
+    }
+#undef OCC_LNB_N
+#undef OCC_LNB
+    OCC_LAUNCH_CHECK("occ_layernorm_bwd");
     return OCC_OK;
 }
 
 int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
                       float* dbeta, int64_t rows, int64_t C, float eps, void* stream) {
-    OCC_CHECK_ARG(dy && x && gamma && dx && dgamma && dbeta, "occ_layernorm_bwd: null pointer");
-    OCC_CHECK_ARG(rows >= 1 && C >= 8 && C % 8 == 0 && C <= 2048, "occ_layernorm_bwd: C must be a multiple of 8 in [8,2048]");
-    OCC_CHECK_ARG(dy_dtype == OCC_F32 || dy_dtype == OCC_BF16, "occ_layernorm_bwd: dy must be f32 or bf16");
-    long long blocks = occ_cdiv(rows, 4 * 8);           // >= 8 rows per wave so the per-workgroup atomics amortise
-    if (blocks > 256) blocks = 256;
-    if (blocks < 1) blocks = 1;
-    const int nit = (int)((C + 511) / 512);
-    hipStream_t s = (hipStream_t)stream;
-#define OCC_LNB(T, N) hipLaunchKernelGGL((layernorm_bwd_kernel<T, N>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)dy, x, gamma, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, (long long)rows, (int)C, eps)
-    if (dy_dtype == OCC_F32) { if (nit == 1) OCC_LNB(float, 1); else if (nit == 2) OCC_LNB(float, 2); else if (nit == 3) OCC_LNB(float, 3); else OCC_LNB(float, 4); }
-    else { if (nit == 1) OCC_LNB(unsigned short, 1); else if (nit == 2) OCC_LNB(unsigned short, 2); else if (nit == 3) OCC_LNB(unsigned short, 3); else OCC_LNB(unsigned short, 4); }
-#undef OCC_LNB
-    OCC_LAUNCH_CHECK("occ_layernorm_bwd");
-    return OCC_OK;
+    return occ_layernorm_bwd_ex(dy, dy_dtype, x, OCC_F32, gamma, nullptr, dres, dx, dx_bf16, nullptr, dgamma, dbeta, rows, C, eps, 0, stream);
 }
 
 int occ_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H, int64_t hd,
@@ -381,6 +572,57 @@ int occ_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
     hipLaunchKernelGGL(attention_bwd_kernel, dim3((unsigned)(B * H)), dim3(256), shm, (hipStream_t)stream, (const unsigned short*)qkv, (const unsigned short*)o,
                        (const unsigned short*)dout, lse, (unsigned short*)dqkv, (int)T, (int)H, (long long)ld_qkv, (long long)ld_o, scale);
     OCC_LAUNCH_CHECK("occ_attention_bwd");
+    return OCC_OK;
+}
+
+int occ_gelu_bwd_rows(const float* dy, const void* u, void* out, const occ_rowmap* out_map, int64_t rows, int64_t C, void* stream) {
+    OCC_CHECK_ARG(dy && u && out && out_map && rows >= 1 && C >= 4 && C % 4 == 0 && out_map->rows_per_batch >= 1, "occ_gelu_bwd_rows: bad argument");
+    long long blocks = occ_cdiv(rows * (C / 4), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gelu_bwd_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, (const unsigned short*)u, (unsigned short*)out,
+                       to_rowmap(*out_map), (long long)rows, (int)C);
+    OCC_LAUNCH_CHECK("occ_gelu_bwd_rows");
+    return OCC_OK;
+}
+
+int occ_conv0_ln_gelu_bwd(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta, const void* dact, int dact_dtype,
+                          float* dw, float* dbias, float* dgamma, float* dbeta, int64_t B, int64_t L, int64_t Tout, int64_t C, int64_t k, int64_t stride,
+                          float eps, void* stream) {
+    OCC_CHECK_ARG(wav && w && bias && gamma && beta && dact && dw && dbias && dgamma && dbeta, "occ_conv0_ln_gelu_bwd: null pointer");
+    OCC_CHECK_ARG(C == 512 && k >= 1 && k <= C0B_MAXK && stride >= 1 && stride <= 16 && B >= 1 && B < 65536 && Tout == (L - k) / stride + 1,
+                  "occ_conv0_ln_gelu_bwd: bad shape");
+    OCC_CHECK_ARG(dact_dtype == OCC_F32 || dact_dtype == OCC_BF16, "occ_conv0_ln_gelu_bwd: dact must be f32 or bf16");
+    const int nsamp = (int)((C0B_FRAMES - 1) * stride + k);
+    const size_t shm = ((size_t)((nsamp + 3) & ~3) + (size_t)3 * 512 * (k + 3)) * sizeof(float);
+    const dim3 grid((unsigned)occ_cdiv(Tout, C0B_FRAMES), (unsigned)B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (dact_dtype == OCC_F32) {
+        e = hipFuncSetAttribute((const void*)conv0_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) { occ_set_error("occ_conv0_ln_gelu_bwd: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+        hipLaunchKernelGGL(conv0_bwd_kernel<float>, grid, block, shm, s, wav, w, bias, gamma, beta, (const float*)dact, dw, dbias, dgamma, dbeta, (int)L, (int)Tout, (int)k, (int)stride, eps);
+    } else {
+        e = hipFuncSetAttribute((const void*)conv0_bwd_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) { occ_set_error("occ_conv0_ln_gelu_bwd: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+        hipLaunchKernelGGL(conv0_bwd_kernel<unsigned short>, grid, block, shm, s, wav, w, bias, gamma, beta, (const unsigned short*)dact, dw, dbias, dgamma, dbeta, (int)L, (int)Tout, (int)k, (int)stride, eps);
+    }
+    OCC_LAUNCH_CHECK("occ_conv0_ln_gelu_bwd");
+    return OCC_OK;
+}
+
+int occ_weight_norm_pack(const float* v, const float* g, void* w_fwd, void* w_bwd, float* norms, int64_t O, int64_t I, int64_t K, int64_t G, void* stream) {
+    OCC_CHECK_ARG(v && g && w_fwd && norms && O >= 1 && I >= 1 && K >= 1 && G >= 1 && O % G == 0, "occ_weight_norm_pack: bad argument");
+    hipLaunchKernelGGL(weight_norm_pack_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, v, g, (unsigned short*)w_fwd, (unsigned short*)w_bwd, norms,
+                       (int)O, (int)I, (int)K, (int)G);
+    OCC_LAUNCH_CHECK("occ_weight_norm_pack");
+    return OCC_OK;
+}
+
+int occ_weight_norm_bwd(const float* v, const float* g, const float* norms, const float* dw_packed, float* dv, float* dg, int64_t O, int64_t I, int64_t K,
+                        int64_t G, void* stream) {
+    OCC_CHECK_ARG(v && g && norms && dw_packed && dv && dg && O >= 1 && I >= 1 && K >= 1 && G >= 1 && O % G == 0, "occ_weight_norm_bwd: bad argument");
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, v, g, norms, dw_packed, dv, dg, (int)O, (int)I, (int)K, (int)G);
+    OCC_LAUNCH_CHECK("occ_weight_norm_bwd");
     return OCC_OK;
 }
 

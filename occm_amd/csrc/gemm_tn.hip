@@ -18,14 +18,20 @@ constexpr int TT = 64, SLAB = 32, LDS_STRIDE = 80, THREADS = 256;
 
 struct TnArgs {
     long long M, N1, N2;
-    const float* A; RowMapI amap;
-    const float* B; RowMapI bmap; long long nseg, seg_len, seg_stride;
+    const void* A; RowMapI amap;
+    const void* B; RowMapI bmap; long long nseg, seg_len, seg_stride;
     float* C; long long ldc;
     long long rows_per_split;
     float alpha;
     float* colsum;            // optional: colsum[n1] += alpha * sum_m A[m, n1] (bias gradient), done by the n2-tile-0 workgroups
 };
 
+__device__ __forceinline__ float4 ld4_bf16(const unsigned short* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <bool ABF, bool BBF>      // operands f32 or bf16 in memory; the MFMA is the exact-f32 one either way
 __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
     __shared__ __attribute__((aligned(16))) float As[SLAB * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float Bs[SLAB * LDS_STRIDE];
@@ -58,8 +64,10 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
             const long long m = m0 + srow + 16 * i;
             va[i] = make_float4(0.f, 0.f, 0.f, 0.f); vb[i] = va[i];
             if (m < m_end) {
-                if (a_ok) va[i] = *reinterpret_cast<const float4*>(a.A + row_off(a.amap, m) + n1c);
-                if (b_ok) vb[i] = *reinterpret_cast<const float4*>(a.B + row_off(a.bmap, m) + bseg_off);
+                if (a_ok) va[i] = ABF ? ld4_bf16((const unsigned short*)a.A + row_off(a.amap, m) + n1c)
+                                      : *reinterpret_cast<const float4*>((const float*)a.A + row_off(a.amap, m) + n1c);
+                if (b_ok) vb[i] = BBF ? ld4_bf16((const unsigned short*)a.B + row_off(a.bmap, m) + bseg_off)
+                                      : *reinterpret_cast<const float4*>((const float*)a.B + row_off(a.bmap, m) + bseg_off);
             }
         }
         csum.x += va[0].x + va[1].x; csum.y += va[0].y + va[1].y; csum.z += va[0].z + va[1].z; csum.w += va[0].w + va[1].w;
@@ -143,8 +151,8 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
     OCC_CHECK_ARG(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0 && d->ldc >= d->N2, "occ_gemm_tn: alignment / ldc");
     TnArgs a;
     a.M = d->M; a.N1 = d->N1; a.N2 = d->N2;
-    a.A = (const float*)d->A; a.amap = to_rowmap(d->a_map);
-    a.B = (const float*)d->B; a.bmap = to_rowmap(d->b_map); a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->b_seg_stride;
+    a.A = d->A; a.amap = to_rowmap(d->a_map);
+    a.B = d->B; a.bmap = to_rowmap(d->b_map); a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->b_seg_stride;
     a.C = (float*)d->C; a.ldc = d->ldc; a.alpha = d->alpha; a.colsum = (float*)d->colsum;
     const long long t1 = occ_cdiv(d->N1, TT), t2 = occ_cdiv(d->N2, TT);
     long long split = occ_cdiv(1024, t1 * t2);                       // aim at ~1024 workgroups
@@ -155,7 +163,14 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
     a.rows_per_split = occ_cdiv(occ_cdiv(d->M, split), SLAB) * SLAB;
     split = occ_cdiv(d->M, a.rows_per_split);
     OCC_CHECK_ARG(t1 < 65536 && t2 < 65536, "occ_gemm_tn: output too large");
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)t1, (unsigned)t2, (unsigned)split), dim3(THREADS), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)t1, (unsigned)t2, (unsigned)split);
+    const bool abf = d->a_dtype == OCC_BF16, bbf = d->b_dtype == OCC_BF16;
+    OCC_CHECK_ARG((abf || d->a_dtype == OCC_F32) && (bbf || d->b_dtype == OCC_F32), "occ_gemm_tn: operand dtypes must be f32 or bf16");
+    hipStream_t s = (hipStream_t)stream;
+    if (abf && bbf) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, dim3(THREADS), 0, s, a);
+    else if (abf) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, dim3(THREADS), 0, s, a);
+    else if (bbf) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, dim3(THREADS), 0, s, a);
     OCC_LAUNCH_CHECK("occ_gemm_tn");
     return OCC_OK;
 }

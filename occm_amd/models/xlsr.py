@@ -231,8 +231,10 @@ class SSLModel(torch.nn.Module):
         if missing:
             raise OccError("XLS-R state_dict lacks %d tensors, e.g. %s" % (len(missing), sorted(missing)[:3]))
         self.finetune = finetune
-        if finetune:        # the reference's optimizer holds the SSL parameters too (oc_training.py:324): trainable encoder
+        if finetune == "encoder":      # transformer encoder trainable, conv feature extractor frozen (feature_grad_mult = 0 style)
             self.model = XlsrFineTuner(self._params, self.cfg, device=device)
+        elif finetune:                 # the reference's optimizer holds every SSL parameter (oc_training.py:324): end-to-end
+            self.model = XlsrFullFineTuner(self._params, self.cfg, device=device)
         else:
             self.model = XlsrFrontend(self._params, self.cfg, device=device, dtype=dtype)
 
@@ -291,6 +293,7 @@ class XlsrFineTuner(XlsrFrontend):
                              ("l%d.ln1.g" % i, (D,)), ("l%d.ln1.b" % i, (D,)), ("l%d.fc1.w" % i, (Fd, D)), ("l%d.fc1.b" % i, (Fd,)),
                              ("l%d.fc2.w" % i, (D, Fd)), ("l%d.fc2.b" % i, (D,)), ("l%d.ln2.g" % i, (D,)), ("l%d.ln2.b" % i, (D,))]
         self.tshapes += [("enc_ln.g", (D,)), ("enc_ln.b", (D,))]
+        self.tshapes += self._extra_shapes()
         off, self.tslots = 0, {}
         for name, shp in self.tshapes:
             nel = 1
@@ -304,14 +307,24 @@ class XlsrFineTuner(XlsrFrontend):
         self.mg = {k: self.G[o:o + nel].view(shp) for k, (o, shp, nel) in self.tslots.items()}
         self._load_master(params)
         self.wT = {}
-        for name, shp in self.tshapes:
+        self._alloc_operands()
+        self.refresh_operands()
+        self.ctx = None
+
+    def _extra_shapes(self):
+        return []
+
+    def _encoder_names(self):
+        return [n for n, _ in self.tshapes if n.startswith("l") and n[1].isdigit() or n.startswith("enc_ln")]
+
+    def _alloc_operands(self):
+        for name in self._encoder_names():
+            shp = self.tslots[name][1]
             if name.endswith(".w"):
                 self.wT[name] = torch.empty(shp[1], shp[0], device=self.device, dtype=torch.bfloat16)
                 self.w[name] = torch.empty(shp, device=self.device, dtype=torch.bfloat16)
             else:
                 self.w[name] = self.mp[name]                    # biases / LayerNorm affine are used in f32 directly
-        self.refresh_operands()
-        self.ctx = None
 
     def _load_master(self, p):
         with torch.no_grad():
@@ -331,7 +344,8 @@ class XlsrFineTuner(XlsrFrontend):
     def refresh_operands(self):
         """bf16 W and W^T from the f32 masters (after every optimizer step)."""
         from .._lib import check, lib, ptr, stream_ptr
-        for name, shp in self.tshapes:
+        for name in self._encoder_names():
+            shp = self.tslots[name][1]
             if name.endswith(".w"):
                 src = self.mp[name]
                 check(lib().occ_cast(ptr(src), OCC_F32, ptr(self.w[name]), dtype_code(self.w[name]), src.numel(), stream_ptr()), "occ_cast")
@@ -490,3 +504,238 @@ class XlsrFineTuner(XlsrFrontend):
             ops.gemm_raw(M, D, 3 * D, tr["dqkv"], qmap, self.wT["l%d.qkv.w" % i], 3 * D, tr["dh"], xmap, bfc, bfc)
             ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i], dx_bf16=dxb)
         self.ctx = None
+
+
+class XlsrFullFineTuner(XlsrFineTuner):
+    """End-to-end trainable XLS-R: conv feature extractor, LayerNorm, projection, weight-normed positional conv AND the
+    transformer encoder (what the reference's optimizer holds, oc_training.py:324).
+
+    Conv blocks 1-6 backward: LayerNorm+GELU backward fused in one row kernel (the pre-LN conv output is kept in bf16); weight
+    gradients as bf16 MFMA GEMMs over transposed operands, where the transposed *window* operand is k strided transposes of the
+    previous activation; input gradients as plain GEMMs over the zero-padded output gradient -- even input frames take taps
+    (2, 0) from two consecutive output rows, odd frames tap 1 (k=3, s=2), or both taps of one row (k=2, s=2).  Block 0 is
+    recomputed from the waveform in its backward kernel.  The positional conv differentiates through weight_norm."""
+
+    def _extra_shapes(self):
+        cfg = self.cfg
+        shp = [("c0.w", (512, 10)), ("c0.b", (512,)), ("c0.g", (512,)), ("c0.be", (512,))]
+        for i in range(1, 7):
+            k = CONV_LAYERS[i][1]
+            shp += [("c%d.w" % i, (512, k, 512)), ("c%d.b" % i, (512,)), ("c%d.g" % i, (512,)), ("c%d.be" % i, (512,))]
+        shp += [("ln.g", (512,)), ("ln.b", (512,)), ("proj.w", (cfg.dim, 512)), ("proj.b", (cfg.dim,)),
+                ("pos.v", (cfg.dim, cfg.dim // cfg.pos_groups, cfg.pos_k)), ("pos.g", (cfg.pos_k,)), ("pos.b", (cfg.dim,))]
+        return shp
+
+    def __init__(self, params, cfg, device="cuda"):
+        self._full = True
+        super().__init__(params, cfg, device=device)
+
+    # hooks used by XlsrFineTuner.__init__ -------------------------------------------------------------------------
+    def _load_master(self, p):
+        super()._load_master(p)
+        f = lambda t: t.detach().to(self.device, torch.float32)
+        with torch.no_grad():
+            for i, (c, k, s) in enumerate(CONV_LAYERS):
+                pre = "feature_extractor.conv_layers.%d" % i
+                w = f(p[pre + ".0.weight"])
+                self.mp["c%d.w" % i].copy_(w.reshape(512, -1) if i == 0 else w.permute(0, 2, 1))
+                self.mp["c%d.b" % i].copy_(f(p[pre + ".0.bias"]))
+                self.mp["c%d.g" % i].copy_(f(p[pre + ".2.1.weight"])); self.mp["c%d.be" % i].copy_(f(p[pre + ".2.1.bias"]))
+            self.mp["ln.g"].copy_(f(p["layer_norm.weight"])); self.mp["ln.b"].copy_(f(p["layer_norm.bias"]))
+            self.mp["proj.w"].copy_(f(p["post_extract_proj.weight"])); self.mp["proj.b"].copy_(f(p["post_extract_proj.bias"]))
+            self.mp["pos.v"].copy_(f(p["encoder.pos_conv.0.weight_v"])); self.mp["pos.g"].copy_(f(p["encoder.pos_conv.0.weight_g"]).reshape(-1))
+            self.mp["pos.b"].copy_(f(p["encoder.pos_conv.0.bias"]))
+
+    def _alloc_operands(self):
+        super()._alloc_operands()
+        cfg, dev, bf = self.cfg, self.device, torch.bfloat16
+        for name in ("c0.w", "c0.b", "c0.g", "c0.be", "ln.g", "ln.b", "proj.b", "pos.b"):
+            self.w[name] = self.mp[name]
+        for i in range(1, 7):
+            k = CONV_LAYERS[i][1]
+            for n in ("b", "g", "be"):
+                self.w["c%d.%s" % (i, n)] = self.mp["c%d.%s" % (i, n)]
+            self.w["c%d.w" % i] = torch.empty(512, k * 512, device=dev, dtype=bf)
+            if k == 3:
+                self.wT["c%d.we" % i] = torch.empty(512, 1024, device=dev, dtype=bf)      # [c][ (tap 2 | tap 0) x n ]
+                self.wT["c%d.wo" % i] = torch.empty(512, 512, device=dev, dtype=bf)       # tap 1
+            else:
+                self.wT["c%d.wt" % i] = torch.empty(k * 512, 512, device=dev, dtype=bf)   # [(tap, c)][n]
+        self.w["proj.w"] = torch.empty(cfg.dim, 512, device=dev, dtype=bf)
+        self.wT["proj.w"] = torch.empty(512, cfg.dim, device=dev, dtype=bf)
+        G, cg = cfg.pos_groups, cfg.dim // cfg.pos_groups
+        self.w["pos.w"] = torch.empty(G, cg, cfg.pos_k * cg, device=dev, dtype=bf)
+        self.wT["pos.w"] = torch.empty(G, cg, cfg.pos_k * cg, device=dev, dtype=bf)
+        self.pos_norms = torch.empty(cfg.pos_k, device=dev, dtype=torch.float32)
+        self.pos_dw = torch.empty(G, cg, cfg.pos_k * cg, device=dev, dtype=torch.float32)
+
+    def refresh_operands(self):
+        super().refresh_operands()
+        from .._lib import check, lib, ptr, stream_ptr
+        cfg = self.cfg
+        for i in range(1, 7):
+            k = CONV_LAYERS[i][1]
+            src = self.mp["c%d.w" % i]                       # [n][tap][c]
+            check(lib().occ_cast(ptr(src), OCC_F32, ptr(self.w["c%d.w" % i]), OCC_BF16_CODE, src.numel(), stream_ptr()), "occ_cast")
+            es = 4
+            if k == 3:
+                we, wo = self.wT["c%d.we" % i], self.wT["c%d.wo" % i]
+                # dst[c][n] = src[n][tap][c]: a transpose of the [512 x 512] slice with row stride k*512
+                ops.transpose_bf16(src.data_ptr() + 2 * 512 * es, we, 512, 512, ld_src=k * 512, ld_dst=1024, src_dtype=OCC_F32)
+                ops.transpose_bf16(src.data_ptr() + 0 * 512 * es, we.data_ptr() + 512 * 2, 512, 512, ld_src=k * 512, ld_dst=1024, src_dtype=OCC_F32)
+                ops.transpose_bf16(src.data_ptr() + 1 * 512 * es, wo, 512, 512, ld_src=k * 512, ld_dst=512, src_dtype=OCC_F32)
+            else:
+                ops.transpose_bf16(src, self.wT["c%d.wt" % i], 512, k * 512, ld_src=k * 512, ld_dst=512)
+        pw = self.mp["proj.w"]
+        check(lib().occ_cast(ptr(pw), OCC_F32, ptr(self.w["proj.w"]), OCC_BF16_CODE, pw.numel(), stream_ptr()), "occ_cast")
+        ops.transpose_bf16(pw, self.wT["proj.w"], cfg.dim, 512, ld_src=512, ld_dst=cfg.dim)
+        G, cg = cfg.pos_groups, cfg.dim // cfg.pos_groups
+        check(lib().occ_weight_norm_pack(ptr(self.mp["pos.v"]), ptr(self.mp["pos.g"]), ptr(self.w["pos.w"]), ptr(self.wT["pos.w"]), ptr(self.pos_norms),
+                                         cfg.dim, cg, cfg.pos_k, G, stream_ptr()), "occ_weight_norm_pack")
+
+    def _names_extra(self):
+        out = {}
+        for i in range(7):
+            pre = "feature_extractor.conv_layers.%d" % i
+            out[pre + ".0.weight"] = ("c%d.w" % i, (lambda t, i=i: t.reshape(512, 1, 10) if i == 0 else t.permute(0, 2, 1).contiguous()))
+            out[pre + ".0.bias"] = ("c%d.b" % i, None); out[pre + ".2.1.weight"] = ("c%d.g" % i, None); out[pre + ".2.1.bias"] = ("c%d.be" % i, None)
+        out["layer_norm.weight"] = ("ln.g", None); out["layer_norm.bias"] = ("ln.b", None)
+        out["post_extract_proj.weight"] = ("proj.w", None); out["post_extract_proj.bias"] = ("proj.b", None)
+        out["encoder.pos_conv.0.weight_v"] = ("pos.v", None); out["encoder.pos_conv.0.weight_g"] = ("pos.g", lambda t: t.reshape(1, 1, -1))
+        out["encoder.pos_conv.0.bias"] = ("pos.b", None)
+        return out
+
+    def export_params(self):
+        out = super().export_params()
+        for k, (n, fn) in self._names_extra().items():
+            t = self.mp[n].clone()
+            out[k] = fn(t) if fn else t
+        return out
+
+    def grad_dict(self):
+        out = super().grad_dict()
+        for k, (n, fn) in self._names_extra().items():
+            t = self.mg[n].clone()
+            out[k] = fn(t) if fn else t
+        return out
+
+    # ------------------------------------------------------------------------------------------ workspaces
+    def _train_ws(self, B, L):
+        ws = super()._train_ws(B, L)
+        tr = ws["tr"]
+        if "conv" not in tr:
+            cfg, dev, bf = self.cfg, self.device, torch.bfloat16
+            Ts, T, M, D = ws["Ts"], ws["T"], ws["M"], cfg.dim
+            e = lambda *s, dt=bf: torch.empty(*s, device=dev, dtype=dt)
+            z = lambda *s, dt=bf: torch.zeros(*s, device=dev, dtype=dt)
+            cv = {"act": [e(B, Ts[i], 512) for i in range(7)], "pre": [None] + [e(B * Ts[i], 512) for i in range(1, 7)],
+                  "dact": [z(B, Ts[i], 512) for i in range(7)], "dpre": [None] + [z(B, Ts[i] + 2, 512) for i in range(1, 7)]}
+            # per-layer transposed operands: their pad columns [R, Mp) must stay zero, so the buffers are not shared across layers
+            cv["tA"] = [None] + [z(512, (B * Ts[i] + 63) // 64 * 64) for i in range(1, 7)]
+            cv["tB"] = [None] + [z(CONV_LAYERS[i][1] * 512, (B * Ts[i] + 63) // 64 * 64) for i in range(1, 7)]
+            cv["lnfeat"] = e(M, 512)
+            cv["u_pos"] = e(M, D)
+            cv["dupad"] = z(B, T + cfg.pos_k, D)
+            cv["dln"] = e(M, 512)
+            cv["tA_proj"], cv["tB_proj"] = z(D, tr["Mp"]), z(512, tr["Mp"])
+            tr["conv"] = cv
+        return ws
+
+    def _frozen_prefix(self, wav, ws):
+        """Trainable prefix in this class: same arithmetic, but every intermediate backward needs is kept."""
+        cfg, w = self.cfg, self.w
+        cv = ws["tr"]["conv"]
+        wav = wav.to(self.device, torch.float32).contiguous()
+        cv["wav"] = wav
+        B, L = wav.shape
+        Ts, T, M, D = ws["Ts"], ws["T"], ws["M"], cfg.dim
+        code = OCC_BF16_CODE
+        ops.conv0_ln_gelu(wav, w["c0.w"], w["c0.b"], w["c0.g"], w["c0.be"], 10, 5, torch.bfloat16, out=cv["act"][0])
+        for i in range(1, 7):
+            _, k, s = CONV_LAYERS[i]
+            Tin, Tout = Ts[i - 1], Ts[i]
+            ops.gemm_raw(B * Tout, 512, k * 512, cv["act"][i - 1], rowmap(Tout, Tin * 512, s * 512), w["c%d.w" % i], k * 512, cv["pre"][i],
+                         rowmap(B * Tout, 0, 512), code, code, bias=w["c%d.b" % i])
+            ops.layernorm(cv["pre"][i], w["c%d.g" % i], w["c%d.be" % i], gelu=True, out=cv["act"][i].view(B * Tout, 512))
+        ops.layernorm(cv["act"][6].view(M, 512), w["ln.g"], w["ln.b"], out=cv["lnfeat"])
+        xpad = ws["xpad"]
+        Tp, half = T + cfg.pos_k, cfg.pos_k // 2
+        inner = xpad.data_ptr() + half * D * xpad.element_size()
+        pmap = rowmap(T, Tp * D, D)
+        ops.gemm_raw(M, D, 512, cv["lnfeat"], rowmap(M, 0, 512), w["proj.w"], 512, inner, pmap, code, code, bias=w["proj.b"])
+        G, cg = cfg.pos_groups, D // cfg.pos_groups
+        ops.gemm_raw(M, cg, cfg.pos_k * cg, xpad, pmap, w["pos.w"], cfg.pos_k * cg, ws["x"], rowmap(M, 0, D), OCC_F32, code, bias=w["pos.b"], act=ACT_GELU,
+                     R=inner, r_map=pmap, r_dtype=code, a_seg=(cfg.pos_k, cg, D), groups=(G, cg, cg * cfg.pos_k * cg, cg), aux=cv["u_pos"])
+
+    def backward(self, dfeats):
+        B, L = self.ctx
+        super().backward(dfeats)                       # leaves d(loss)/d(encoder input) in tr["dx"]
+        from .. import backend_ops as K
+        from .._lib import check, lib, ptr, stream_ptr
+        cfg, w = self.cfg, self.w
+        ws = self._workspace(B, L, slot=0)
+        tr = ws["tr"]
+        cv = tr["conv"]
+        Ts, T, M, D, Mp = ws["Ts"], ws["T"], ws["M"], cfg.dim, tr["Mp"]
+        bfc = OCC_BF16_CODE
+        G, cg, Kp = cfg.pos_groups, D // cfg.pos_groups, cfg.pos_k
+        Tp = T + Kp
+        dx = tr["dx"]
+        xpad, dupad = ws["xpad"], cv["dupad"]
+        # ---- positional conv: x = x0 + gelu(conv(x0) + b) --------------------------------------------------------
+        du_in = dupad.data_ptr() + (Kp // 2 - 1) * D * 2          # interior starts 63 rows in (K/2 - 1)
+        dmap = rowmap(T, Tp * D, D)
+        check(lib().occ_gelu_bwd_rows(ptr(dx), ptr(cv["u_pos"]), du_in, ctypes_byref(dmap), M, D, stream_ptr()), "occ_gelu_bwd_rows")
+        K.fill(self.pos_dw.view(-1), 0.0)
+        for g in range(G):
+            K.gemm_tn(M, cg, Kp * cg, du_in + g * cg * 2, dmap, xpad.data_ptr() + g * cg * 2, dmap, self.pos_dw[g], Kp * cg, b_seg=(Kp, cg, D),
+                      colsum_out=self.mg["pos.b"][g * cg:(g + 1) * cg], a_bf16=True, b_bf16=True)
+        check(lib().occ_weight_norm_bwd(ptr(self.mp["pos.v"]), ptr(self.mp["pos.g"]), ptr(self.pos_norms), ptr(self.pos_dw), ptr(self.mg["pos.v"]),
+                                        ptr(self.mg["pos.g"]), D, cg, Kp, G, stream_ptr()), "occ_weight_norm_bwd")
+        xm = rowmap(M, 0, D)
+        ops.gemm_raw(M, cg, Kp * cg, dupad, dmap, self.wT["pos.w"], Kp * cg, dx, xm, OCC_F32, bfc, R=dx, r_map=xm, r_dtype=OCC_F32,
+                     a_seg=(Kp, cg, D), groups=(G, cg, cg * Kp * cg, cg))
+        # ---- post_extract_proj + LayerNorm(512) --------------------------------------------------------------------
+        ops.transpose_bf16(dx, cv["tA_proj"], M, D, ld_src=D, ld_dst=Mp, colsum=self.mg["proj.b"])
+        ops.transpose_bf16(cv["lnfeat"], cv["tB_proj"], M, 512, ld_src=512, ld_dst=Mp)
+        gw = self.mg["proj.w"]
+        ops.gemm_raw(D, 512, Mp, cv["tA_proj"], rowmap(D, 0, Mp), cv["tB_proj"], Mp, gw, rowmap(D, 0, 512), OCC_F32, bfc, R=gw, r_map=rowmap(D, 0, 512), r_dtype=OCC_F32)
+        ops.gemm_raw(M, 512, D, dx, xm, self.wT["proj.w"], D, cv["dln"], rowmap(M, 0, 512), bfc, OCC_AF32_WBF16)
+        ops.layernorm_bwd_ex(cv["dln"], cv["act"][6].view(M, 512), w["ln.g"], None, None, None, cv["dact"][6].view(M, 512), None, self.mg["ln.g"], self.mg["ln.b"], gelu=False)
+        # ---- conv blocks 6..1 ------------------------------------------------------------------------------------------
+        for i in range(6, 0, -1):
+            _, k, s = CONV_LAYERS[i]
+            Tin, Tout = Ts[i - 1], Ts[i]
+            R = B * Tout
+            Mpi = (R + 63) // 64 * 64
+            dpre = cv["dpre"][i]
+            d_in = dpre.data_ptr() + 512 * 2                                   # interior: one zero row in front of every utterance
+            imap = rowmap(Tout, (Tout + 2) * 512, 512)
+            ops.layernorm_bwd_ex(cv["dact"][i].view(R, 512), cv["pre"][i], w["c%d.g" % i], w["c%d.be" % i], None, None, d_in, imap,
+                                 self.mg["c%d.g" % i], self.mg["c%d.be" % i], gelu=True)
+            # weight gradient: dW[n][(tap,c)] = sum_m dpre[m][n] * act_{i-1}[b, s*t + tap, c]
+            tA, tB = cv["tA"][i], cv["tB"][i]
+            ldT = tA.shape[1]
+            ops.transpose_bf16_rows(d_in, imap, tA, R, 512, ld_dst=ldT, colsum=self.mg["c%d.b" % i], src_dtype=bfc)
+            for tap in range(k):
+                ops.transpose_bf16_rows(cv["act"][i - 1].data_ptr() + tap * 512 * 2, rowmap(Tout, Tin * 512, s * 512), tB.data_ptr() + tap * 512 * ldT * 2, R, 512,
+                                        ld_dst=ldT, src_dtype=bfc)
+            gwi = self.mg["c%d.w" % i].view(512, k * 512)
+            ops.gemm_raw(512, k * 512, Mpi, tA, rowmap(512, 0, ldT), tB, ldT, gwi, rowmap(512, 0, k * 512), OCC_F32, bfc, R=gwi, r_map=rowmap(512, 0, k * 512), r_dtype=OCC_F32)
+            # input gradient
+            dprev = cv["dact"][i - 1]
+            if k == 3:
+                ne, no = (Tin + 1) // 2, Tin // 2
+                ops.gemm_raw(B * ne, 512, 1024, dpre, rowmap(ne, (Tout + 2) * 512, 512), self.wT["c%d.we" % i], 1024, dprev, rowmap(ne, Tin * 512, 1024), bfc, bfc)
+                ops.gemm_raw(B * no, 512, 512, d_in, rowmap(no, (Tout + 2) * 512, 512), self.wT["c%d.wo" % i], 512, dprev.data_ptr() + 512 * 2, rowmap(no, Tin * 512, 1024), bfc, bfc)
+            else:
+                ops.gemm_raw(R, k * 512, 512, d_in, imap, self.wT["c%d.wt" % i], 512, dprev, rowmap(Tout, Tin * 512, k * 512), bfc, bfc)
+        # ---- conv block 0 (recomputed from the waveform) --------------------------------------------------------------------
+        check(lib().occ_conv0_ln_gelu_bwd(ptr(cv["wav"]), ptr(w["c0.w"]), ptr(w["c0.b"]), ptr(w["c0.g"]), ptr(w["c0.be"]), ptr(cv["dact"][0]), bfc,
+                                          ptr(self.mg["c0.w"]), ptr(self.mg["c0.b"]), ptr(self.mg["c0.g"]), ptr(self.mg["c0.be"]), B, L, Ts[0], 512, 10, 5,
+                                          1e-5, stream_ptr()), "occ_conv0_ln_gelu_bwd")
+
+
+def ctypes_byref(m):
+    import ctypes
+    return ctypes.byref(m)

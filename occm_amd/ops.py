@@ -123,12 +123,37 @@ def attention_bwd(qkv, o, dout, lse, B, T, H, hd, scale, dqkv=None):
     return dqkv
 
 
-def transpose_bf16(src, dst, rows, cols, ld_src=None, ld_dst=None, colsum=None):
+def _p(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t) if isinstance(t, int) else ctypes.c_void_p(t.data_ptr())
+
+
+def transpose_bf16(src, dst, rows, cols, ld_src=None, ld_dst=None, colsum=None, src_dtype=None):
     """dst[c, r] = bf16(src[r, c]); dst is a bf16 [cols, ld_dst] buffer whose pad columns the caller keeps at zero.
-    colsum (optional f32 [cols]) accumulates the column sums of src (bias gradient)."""
-    check(lib().occ_transpose_bf16(ptr(src), dtype_code(src), ptr(dst), int(rows), int(cols), int(ld_src or cols), int(ld_dst or dst.shape[-1]),
-                                   ptr(colsum), stream_ptr()), "occ_transpose_bf16")
+    colsum (optional f32 [cols]) accumulates the column sums of src (bias gradient).  src / dst may be int addresses
+    (then src_dtype and ld_dst are required)."""
+    sd = src_dtype if src_dtype is not None else dtype_code(src)
+    check(lib().occ_transpose_bf16(_p(src), sd, _p(dst), int(rows), int(cols), int(ld_src or cols), int(ld_dst or dst.shape[-1]),
+                                   _p(colsum), stream_ptr()), "occ_transpose_bf16")
     return dst
+
+
+def transpose_bf16_rows(src, src_map, dst, rows, cols, ld_dst, colsum=None, src_dtype=None):
+    """Like transpose_bf16 with the source rows addressed through a row map."""
+    sd = src_dtype if src_dtype is not None else dtype_code(src)
+    check(lib().occ_transpose_bf16_rows(_p(src), sd, ctypes.byref(src_map), _p(dst), int(rows), int(cols), int(ld_dst), _p(colsum), stream_ptr()),
+          "occ_transpose_bf16_rows")
+    return dst
+
+
+def layernorm_bwd_ex(dy, x, gamma, beta, dres, dx, dx_bf16, dx_bf16_map, dgamma, dbeta, gelu, eps=1e-5):
+    """General LayerNorm backward (x f32 or bf16, optional fused GELU', f32 and/or row-mapped bf16 outputs)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    check(lib().occ_layernorm_bwd_ex(_p(dy), dtype_code(dy), _p(x), dtype_code(x), _p(gamma), _p(beta), _p(dres), _p(dx), _p(dx_bf16),
+                                     ctypes.byref(dx_bf16_map) if dx_bf16_map is not None else None, _p(dgamma), _p(dbeta), rows, C, float(eps),
+                                     int(gelu), stream_ptr()), "occ_layernorm_bwd_ex")
 
 
 def layernorm_bwd(dy, x, gamma, dres, dx, dgamma, dbeta, eps=1e-5, dx_bf16=None):

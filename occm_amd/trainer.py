@@ -10,8 +10,9 @@ class OcTrainer:
     """model: occm_amd.models.sslassist.AModel.  Loss weights default to the committed 0.0 / 1.0 (oc_training.py:380-381);
     the SE-ResNet script uses 0.1 / 0.9 (test_dataloader_v2.py:127)."""
 
-    def __init__(self, model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=False, group_size=None):
+    def __init__(self, model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=False, group_size=None, dropout_masks=None):
         self.model = model
+        self.dropout_masks = dropout_masks      # None: draw masks on the device (normal training); {}: no dropout; dict: injected keep-masks
         self.be = model.backend
         self.fe = model.ssl_model.model
         self.train_frontend = train_frontend
@@ -34,7 +35,7 @@ class OcTrainer:
             return self._step_finetune(wav, labels)
         feats = self.model.ssl_model.model.forward(wav, out_dtype=torch.float32)
         be.zero_grad()
-        emb, logits = be.forward(feats, train=True)
+        emb, logits = be.forward(feats, train=True, masks=self.dropout_masks)
         B = emb.shape[0]
         ng = 1 if not self.group_size else B // self.group_size
         lc, demb = ops.compactness_loss(emb, n_groups=ng, group=self.group_size or B, scale=self.w_c, want_grad=True)
@@ -49,7 +50,7 @@ class OcTrainer:
         be, fe = self.be, self.fe
         feats = fe.forward_train(wav)
         be.zero_grad(); fe.zero_grad()
-        emb, logits = be.forward(feats, train=True)
+        emb, logits = be.forward(feats, train=True, masks=self.dropout_masks)
         B = emb.shape[0]
         ng = 1 if not self.group_size else B // self.group_size
         lc, demb = ops.compactness_loss(emb, n_groups=ng, group=self.group_size or B, scale=self.w_c, want_grad=True)

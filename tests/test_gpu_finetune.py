@@ -144,9 +144,9 @@ def test_finetune_trainer_runs_and_learns():
     from occm_amd.models.sslassist import AModel
     from occm_amd.trainer import OcTrainer
     cfg = xlsr.XlsrConfig(dim=1024, ffn=512, heads=16, layers=2)      # AASIST's LL expects 1024-d features
-    model = AModel(None, "cuda", ssl_cfg=cfg, finetune_ssl=True, backend_compute="f32")
+    model = AModel(None, "cuda", ssl_cfg=cfg, finetune_ssl="full", backend_compute="f32")
     before = {k: v.clone() for k, v in model.ssl_model.model.export_params().items()}
-    tr = OcTrainer(model, lr=2e-4, w_compact=0.1, w_descr=0.9, train_frontend=True)
+    tr = OcTrainer(model, lr=2e-4, w_compact=0.1, w_descr=0.9, train_frontend=True, dropout_masks={})   # no dropout: deterministic descent
     wav = (0.1 * _r(12, 16000, seed=1)).cuda()
     labels = (torch.arange(12) % 12 >= 6).long().cuda()
     losses = []
@@ -161,3 +161,44 @@ def test_finetune_trainer_runs_and_learns():
         assert "ssl_model.model." + k in sd
         moved += int(not torch.equal(sd["ssl_model.model." + k].cpu(), v.cpu()))
     assert moved == len(before)
+
+
+@pytest.mark.parametrize("L", [4000, 16000])
+def test_full_finetuner_all_gradients_match_oracle_autograd(L):
+    """End-to-end XLS-R backward (conv feature extractor, LayerNorm, projection, weight-normed positional conv, encoder)."""
+    from oracle import xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.models import xlsr
+    kw = dict(dim=256, ffn=512, heads=4, layers=2)
+    rcfg, cfg = xlsr_ref.XlsrConfig(**kw), xlsr.XlsrConfig(**kw)
+    p = fill_like(xlsr_ref.param_shapes(rcfg), seed=3)
+    for v in p.values():
+        v.requires_grad_(True)
+    wav = 0.1 * _r(2, L, seed=5)
+    ref = xlsr_ref.extract_feat(wav, p, rcfg)
+    dfe = _r(*ref.shape, seed=6)
+    (ref * dfe).sum().backward()
+    ft = xlsr.XlsrFullFineTuner({k: v.detach() for k, v in p.items()}, cfg)
+    out = ft.forward_train(wav.cuda())
+    err = (out.cpu() - ref.detach()).abs()
+    assert float(err.max()) < 8e-2 and float(err.mean()) < 1.2e-2, (float(err.max()), float(err.mean()))
+    ft.zero_grad()
+    ft.backward(dfe.cuda())
+    grads = ft.grad_dict()
+    assert set(grads) == set(p.keys())
+    gmax = max(float(v.grad.abs().max()) for v in p.values())
+    bad = []
+    for k, v in p.items():
+        g, r = grads[k].cpu().reshape(-1), v.grad.reshape(-1)
+        if float(r.abs().max()) < 1e-5 * gmax:
+            assert float(g.abs().max()) < 2e-2 * gmax, (k, float(g.abs().max()), gmax)
+            continue
+        cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-30))
+        rel = float((g - r).abs().max() / (r.abs().max() + 1e-30))
+        if cos < 0.99 or rel > 8e-2:
+            bad.append((k, round(cos, 5), round(rel, 4)))
+    assert not bad, bad[:12]
+    ex = ft.export_params()
+    for k, v in p.items():
+        assert tuple(ex[k].shape) == tuple(v.shape), k
+        torch.testing.assert_close(ex[k].cpu(), v.detach())
