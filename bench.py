@@ -127,6 +127,7 @@ def main():
                     help="NOT the headline config: also train XLS-R (full = end-to-end as the reference's optimizer does, BASELINE configs[2] "
                     "minus RawBoost; encoder = transformer only); prints the same JSON with a different workload name")
     ap.add_argument("--bs", type=int, default=BS, help="per-GPU batch (headline: 32)")
+    ap.add_argument("--rawboost", type=int, default=0, help="RawBoost algo 1-8 applied on the GPU inside the timed step (configs[2]: 5)")
     ap.add_argument("--split", type=int, default=1, help="run the front-end as this many concurrent sub-batches on separate HIP "
                     "streams inside the graph; measured slower on MI355X (16.4 / 19.8 / 21.9 ms per step at 1 / 2 / 4), kept for experiments")
     args = ap.parse_args()
@@ -144,7 +145,7 @@ def main():
     bs = args.bs
     model = AModel(None, dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, seed=0, finetune_ssl=args.finetune or False)
     model.train()
-    trainer = OcTrainer(model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=bool(args.finetune))
+    trainer = OcTrainer(model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=bool(args.finetune), rawboost_algo=args.rawboost)
     wav, labels = synth_batch(bs, rank, dev)
     fe = model.ssl_model.model
     if args.finetune:
@@ -224,7 +225,7 @@ def main():
         cpu = cpu_baseline()
     if rank == 0:
         wl = ("XLSR-300M frozen frontend + AASIST backend, bs=%d per GPU, 64000-sample utterances (BASELINE configs[1])" % bs) if not args.finetune else \
-            ("XLSR-300M fine-tuned (%s) + AASIST backend, bs=%d per GPU (BASELINE configs[2] without RawBoost)" % (args.finetune, bs))
+            ("XLSR-300M fine-tuned (%s) + AASIST backend, bs=%d per GPU (BASELINE configs[2]%s)" % (args.finetune, bs, ", RawBoost algo %d on-GPU" % args.rawboost if args.rawboost else " without RawBoost"))
         out = {"metric": "utterances/sec (4 s @16 kHz) training step", "value": round(bs * world * args.steps / dt, 2), "unit": "utterances/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

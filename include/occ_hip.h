@@ -57,6 +57,15 @@ int occ_notch_coeffs_host(const double* fc, const double* bw, const int32_t* c, 
                           double* out_host, int32_t* ntaps_out_host, int64_t max_taps);
 /* out = a + b (f64): the parallel branch sum of RawBoost algo 8 (data_utils_SSL.py:160-165).         */
 int occ_add_f64(const double* a, const double* b, double* out, int64_t n, void* stream);
+/* Device version for a batch of filters: fc, bw f64 [n_filters, n_bands], c i32 [n_filters, n_bands], gain f64 [n_filters] ->
+ * coef f64 [n_filters, max_taps] (zero padded), ntaps i32 [n_filters].  Same arithmetic as occ_notch_coeffs_host.            */
+int occ_notch_coeffs(const double* fc, const double* bw, const int32_t* c, const double* gain, int64_t n_filters, int64_t n_bands,
+                     double fs, double* coef, int32_t* ntaps, int64_t max_taps, void* stream);
+/* ISD_additive_noise with the randomness on the device (Philox): for each utterance b, n[b] positions drawn uniformly without
+ * replacement (radix select of the n[b] smallest per-sample keys) get y *= 1 + g_sd*(2u1-1)(2u2-1).  thr_scratch: u32 [B];
+ * count (optional i32 [B], pre-zeroed) receives the number of touched samples.  Follow with occ_rawboost_center_norm(.., 0, 1, ..). */
+int occ_rawboost_isd_device(double* y, const int32_t* n, uint32_t* thr_scratch, int32_t* count, int64_t B, int64_t L, double g_sd,
+                            uint64_t seed, uint64_t stream_id, void* stream);
 int occ_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 /* Counter-based N(0,1) / U[0,1) fill (Philox4x32-10), element i uses counter (i/4, stream_id).   */
 int occ_philox_fill(void* dst, int dtype, int64_t n, uint64_t seed, uint64_t stream_id, int normal, void* stream);

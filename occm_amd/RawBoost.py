@@ -166,3 +166,83 @@ def SSI_additive_noise(x, SNRmin, SNRmax, nBands, minF, maxF, minBW, maxBW, minC
     t, was_np, sq = _to_dev(x)
     y = _ssi_dev(_as64(t), SNRmin, SNRmax, nBands, minF, maxF, minBW, maxBW, minCoeff, maxCoeff, minG, maxG, fs)
     return _from_dev(y, was_np, sq)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Device mode: everything per-sample happens on the GPU, including the filter design and the random draws that scale with
+# the signal length (ISD positions, SSI noise).  Only the O(100) scalar parameters per utterance come from a host
+# ``np.random.Generator`` (vectorised).  Same distributions as the reference, different random stream -- use the functions
+# above (legacy np.random order) when bit-compatibility with the reference's augmentation is wanted.
+def _design_bank_device(rng, B, n_filt, a, fs, gain_lo, gain_hi, max_taps):
+    """gain_lo / gain_hi: length-n_filt sequences (the LnL bias lowers the gain range for the non-linear branches)."""
+    from ._lib import check, lib, ptr, stream_ptr
+    fc = rng.uniform(a.minF, a.maxF, size=(B, n_filt, a.nBands))
+    bw = rng.uniform(a.minBW, a.maxBW, size=(B, n_filt, a.nBands))
+    c = rng.uniform(a.minCoeff, a.maxCoeff, size=(B, n_filt, a.nBands)).astype(np.int32)
+    G = np.stack([rng.uniform(gain_lo[i], gain_hi[i], size=B) if gain_hi[i] > gain_lo[i] else np.full(B, float(gain_lo[i])) for i in range(n_filt)], axis=1)
+    dev = lambda t: torch.from_numpy(np.ascontiguousarray(t)).cuda()
+    fc_d, bw_d, c_d, g_d = dev(fc), dev(bw), dev(c), dev(G)
+    coef = torch.empty(B, n_filt, max_taps, device="cuda", dtype=torch.float64)
+    ntaps = torch.empty(B, n_filt, device="cuda", dtype=torch.int32)
+    check(lib().occ_notch_coeffs(ptr(fc_d), ptr(bw_d), ptr(c_d), ptr(g_d), B * n_filt, a.nBands, float(fs), ptr(coef), ptr(ntaps), max_taps, stream_ptr()),
+          "occ_notch_coeffs")
+    return coef, ntaps
+
+
+def rawboost_batch_device(x, args, algo, rng=None, seed=0, step=0, fs=16000):
+    """process_Rawboost_feature (data_utils_SSL.py:111-173) for a CUDA batch x f32 [B,L] -> f32 [B,L], randomness on the device."""
+    from ._lib import check, lib, ptr, stream_ptr
+    require_gpu()
+    if algo not in (1, 2, 3, 4, 5, 6, 7, 8):
+        return x
+    a = args
+    rng = rng or np.random.default_rng(seed * 1000003 + step)
+    B, L = x.shape
+    max_taps = max(MAX_TAPS, a.nBands * (int(a.maxCoeff) + 1))
+    sid = [(step << 4) + 1]
+
+    def lnl(v):
+        lo = [a.minG] + [a.minG - a.minBiasLinNonLin] * (a.N_f - 1)             # RawBoost.py:62-64
+        hi = [a.maxG] + [a.maxG - a.maxBiasLinNonLin] * (a.N_f - 1)
+        coef, ntaps = _design_bank_device(rng, B, a.N_f, a, fs, lo, hi, max_taps)
+        y = ops.rawboost_fir_bank(v, coef, ntaps, powers=True)
+        return ops.rawboost_center_norm(y, subtract_mean=True, norm_mode=1)
+
+    def isd(v):
+        y = _as64(v) if v.dtype != torch.float64 else v
+        if y is v:
+            y = v.clone()
+        beta = rng.uniform(0, a.P, size=B)
+        n = torch.from_numpy((L * (beta / 100)).astype(np.int32)).cuda()
+        thr = torch.empty(B, device="cuda", dtype=torch.int32)
+        sid[0] += 1
+        check(lib().occ_rawboost_isd_device(ptr(y), ptr(n), ptr(thr), None, B, L, float(a.g_sd), int(seed), int(sid[0]), stream_ptr()), "occ_rawboost_isd_device")
+        return ops.rawboost_center_norm(y, subtract_mean=False, norm_mode=1)
+
+    def ssi(v):
+        sid[0] += 1
+        noise = ops.philox_fill((B, L), torch.float64, seed, sid[0], normal=True)
+        coef, ntaps = _design_bank_device(rng, B, 1, a, fs, [a.minG], [a.maxG], max_taps)
+        nz = ops.rawboost_fir_bank(noise, coef, ntaps, powers=False)
+        nz = ops.rawboost_center_norm(nz, subtract_mean=False, norm_mode=2)
+        snr = torch.from_numpy(rng.uniform(a.SNRmin, a.SNRmax, size=B)).cuda()
+        return ops.rawboost_ssi_mix(_as64(v), nz, snr)
+
+    t = x.contiguous()
+    if algo == 1:
+        y = lnl(t)
+    elif algo == 2:
+        y = isd(t)
+    elif algo == 3:
+        y = ssi(t)
+    elif algo == 4:
+        y = ssi(isd(lnl(t)))
+    elif algo == 5:
+        y = isd(lnl(t))
+    elif algo == 6:
+        y = ssi(lnl(t))
+    elif algo == 7:
+        y = ssi(isd(t))
+    else:
+        y = ops.rawboost_center_norm(ops.add_f64(lnl(t), isd(t)), subtract_mean=False, norm_mode=1)
+    return ops.cast(y, torch.float32) if y.dtype != torch.float32 else y

@@ -231,6 +231,135 @@ __global__ void philox_fill_kernel(T* __restrict__ dst, int64_t n, uint64_t seed
     }
 }
 
+
+// ---- on-device filter design: genNotchCoeffs (RawBoost.py:28-48) for a batch of filters -----------------------------
+// One workgroup per filter: 5 Hamming-windowed band-stops (scipy firwin) convolved together in LDS, |H| on freqz's
+// 512-point grid by a phasor recurrence, scaled to 10^(G/20) / max|H|.  f64 throughout, like the host version.
+constexpr int NC_THREADS = 512, NC_MAXT = 1024;
+__global__ __launch_bounds__(NC_THREADS) void notch_coeffs_kernel(const double* __restrict__ fc, const double* __restrict__ bw, const int32_t* __restrict__ cc,
+                                                                  const double* __restrict__ gain, int n_bands, double fs, double* __restrict__ coef,
+                                                                  int32_t* __restrict__ ntaps, int max_taps) {
+    __shared__ double b0[NC_MAXT], b1[NC_MAXT], h[128];
+    __shared__ double red[NC_THREADS / 64];
+    __shared__ double bc;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    double* cur = b0; double* nxt = b1;
+    int len = 1;
+    if (tid == 0) cur[0] = 1.0;
+    const double nyq = 0.5 * fs, PI = 3.14159265358979323846;
+    for (int i = 0; i < n_bands; ++i) {
+        int c = cc[f * n_bands + i];
+        if ((c & 1) == 0) c += 1;
+        if (c > 127) c = 127;
+        double f1 = fc[f * n_bands + i] - bw[f * n_bands + i] / 2, f2 = fc[f * n_bands + i] + bw[f * n_bands + i] / 2;
+        if (f1 <= 0) f1 = 1.0 / 1000;
+        if (f2 >= fs / 2) f2 = fs / 2 - 1.0 / 1000;
+        const double lo = f1 / nyq, hi = f2 / nyq, alpha = 0.5 * (c - 1);
+        double v = 0.0;
+        if (tid < c) {
+            const double m = tid - alpha;
+            auto sinc = [&](double x) { const double y = PI * (x == 0.0 ? 1.0e-20 : x); return sin(y) / y; };
+            v = lo * sinc(lo * m);
+            v = v + (1.0 * sinc(1.0 * m) - hi * sinc(hi * m));
+            v *= c == 1 ? 1.0 : 0.54 - 0.46 * cos(2.0 * PI * tid / (c - 1));
+        }
+        double s = wave_sum(v);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < NC_THREADS / 64; ++w) tot += red[w];
+        if (tid < c) h[tid] = v / tot;
+        __syncthreads();
+        const int nl = len + c - 1;                       // np.convolve(h, cur)
+        for (int p = tid; p < nl && p < NC_MAXT; p += NC_THREADS) {
+            double acc = 0.0;
+            const int j0 = p >= len - 1 ? p - (len - 1) : 0;
+            for (int j = j0; j < c && j <= p; ++j) acc += h[j] * cur[p - j];
+            nxt[p] = acc;
+        }
+        __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
+        len = nl < NC_MAXT ? nl : NC_MAXT;
+    }
+    // max |H(e^{jw})|, w = pi*k/512
+    double mag = 0.0;
+    {
+        const int k = tid;                                 // 512 threads = 512 frequencies
+        const double w = PI * k / 512.0, cw = cos(w), sw = sin(w);
+        double re = 0.0, im = 0.0, pr = 1.0, pi_ = 0.0;    // phasor e^{-jwn}
+        for (int n = 0; n < len; ++n) {
+            re += cur[n] * pr; im += cur[n] * pi_;
+            const double npr = pr * cw + pi_ * sw, npi = pi_ * cw - pr * sw;
+            pr = npr; pi_ = npi;
+            if ((n & 63) == 63) { const double nn = pr * pr + pi_ * pi_; const double r = rsqrt(nn); pr *= r; pi_ *= r; }   // keep |phasor| = 1
+        }
+        mag = sqrt(re * re + im * im);
+    }
+    mag = wave_max(mag);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = mag;
+    __syncthreads();
+    if (tid == 0) { double m = red[0]; for (int w = 1; w < NC_THREADS / 64; ++w) m = red[w] > m ? red[w] : m; bc = pow(10.0, gain[f] / 20.0) / m; }
+    __syncthreads();
+    for (int n = tid; n < max_taps; n += NC_THREADS) coef[(size_t)f * max_taps + n] = n < len ? cur[n] * bc : 0.0;
+    if (tid == 0) ntaps[f] = len;
+}
+
+// ---- on-device ISD (RawBoost.py:73-84): exactly-n random positions via a radix select on Philox keys ------------------------
+__device__ __forceinline__ uint32_t isd_key(uint64_t seed, uint64_t sid, int b, int j, int word) {
+    uint32_t r[4];
+    philox4x32_10(((uint64_t)b << 32) | (uint32_t)j, sid, seed, r);
+    return r[word];
+}
+// thr[b] = the n[b]-th smallest key (keys <= thr are selected; ties with thr add at most a handful of extra positions)
+__global__ __launch_bounds__(1024) void isd_select_kernel(const int32_t* __restrict__ n, uint32_t* __restrict__ thr, int L, uint64_t seed, uint64_t sid) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned prefix_s, want_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    unsigned want = (unsigned)n[b];
+    if (want == 0) { if (tid == 0) thr[b] = 0u; return; }
+    if (want > (unsigned)L) want = L;
+    unsigned prefix = 0;                      // bits already fixed (from the top)
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+        __syncthreads();
+        const unsigned hi_mask = pass == 0 ? 0u : (0xffffffffu << (shifts[pass - 1]));
+        for (int j = tid; j < L; j += 1024) {
+            const unsigned key = isd_key(seed, sid, b, j, 0);
+            if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(key >> shifts[pass]) & ((1u << bits[pass]) - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0, bin = 0;
+            const unsigned nb = 1u << bits[pass];
+            for (bin = 0; bin < nb; ++bin) { if (acc + hist[bin] >= want) break; acc += hist[bin]; }
+            if (bin >= nb) bin = nb - 1;
+            prefix_s = prefix | (bin << shifts[pass]);
+            want_s = want - acc;
+        }
+        __syncthreads();
+        prefix = prefix_s; want = want_s;
+        __syncthreads();
+    }
+    if (tid == 0) thr[b] = prefix;
+}
+__global__ void isd_apply_kernel(double* __restrict__ y, const int32_t* __restrict__ n, const uint32_t* __restrict__ thr, int L, double g_sd, uint64_t seed,
+                                 uint64_t sid, int32_t* __restrict__ count) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= L || n[b] <= 0) return;
+    uint32_t r[4];
+    philox4x32_10(((uint64_t)b << 32) | (uint32_t)j, sid, seed, r);
+    if (r[0] > thr[b]) return;
+    const double u1 = (double)r[1] * (1.0 / 4294967296.0), u2 = (double)r[2] * (1.0 / 4294967296.0);
+    double* yp = y + (size_t)b * L + j;
+    const double v = *yp;
+    *yp = v + g_sd * v * ((2.0 * u1 - 1.0) * (2.0 * u2 - 1.0));
+    if (count) atomicAdd(count + b, 1);
+}
+
 }  // namespace
 
 extern "C" {
@@ -319,6 +448,27 @@ int occ_philox_fill(void* dst, int dtype, int64_t n, uint64_t seed, uint64_t str
     else if (dtype == OCC_F64) hipLaunchKernelGGL(philox_fill_kernel<double>, dim3(blocks), dim3(256), 0, s, (double*)dst, n, seed, stream_id, normal);
     else { occ_set_error("occ_philox_fill: dtype must be f32 or f64"); return OCC_EUNSUPPORTED; }
     OCC_LAUNCH_CHECK("occ_philox_fill");
+    return OCC_OK;
+}
+
+int occ_notch_coeffs(const double* fc, const double* bw, const int32_t* c, const double* gain, int64_t n_filters, int64_t n_bands, double fs,
+                     double* coef, int32_t* ntaps, int64_t max_taps, void* stream) {
+    OCC_CHECK_ARG(fc && bw && c && gain && coef && ntaps && n_filters >= 1 && n_bands >= 1 && n_bands <= 8, "occ_notch_coeffs: bad argument");
+    OCC_CHECK_ARG(max_taps >= 1 && max_taps <= NC_MAXT, "occ_notch_coeffs: max_taps must be in [1,%d]", NC_MAXT);
+    hipLaunchKernelGGL(notch_coeffs_kernel, dim3((unsigned)n_filters), dim3(NC_THREADS), 0, (hipStream_t)stream, fc, bw, c, gain, (int)n_bands, fs, coef, ntaps,
+                       (int)max_taps);
+    OCC_LAUNCH_CHECK("occ_notch_coeffs");
+    return OCC_OK;
+}
+
+int occ_rawboost_isd_device(double* y, const int32_t* n, uint32_t* thr_scratch, int32_t* count, int64_t B, int64_t L, double g_sd, uint64_t seed,
+                            uint64_t stream_id, void* stream) {
+    OCC_CHECK_ARG(y && n && thr_scratch && B >= 1 && B < 65536 && L >= 1 && L < (1ll << 30), "occ_rawboost_isd_device: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(isd_select_kernel, dim3((unsigned)B), dim3(1024), 0, s, n, thr_scratch, (int)L, seed, stream_id);
+    hipLaunchKernelGGL(isd_apply_kernel, dim3((unsigned)occ_cdiv(L, 256), (unsigned)B), dim3(256), 0, s, y, n, (const uint32_t*)thr_scratch, (int)L, g_sd, seed,
+                       stream_id, count);
+    OCC_LAUNCH_CHECK("occ_rawboost_isd_device");
     return OCC_OK;
 }
 

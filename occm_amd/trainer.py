@@ -10,8 +10,10 @@ class OcTrainer:
     """model: occm_amd.models.sslassist.AModel.  Loss weights default to the committed 0.0 / 1.0 (oc_training.py:380-381);
     the SE-ResNet script uses 0.1 / 0.9 (test_dataloader_v2.py:127)."""
 
-    def __init__(self, model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=False, group_size=None, dropout_masks=None):
+    def __init__(self, model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=False, group_size=None, dropout_masks=None, rawboost_algo=0,
+                 rawboost_args=None, seed=0):
         self.model = model
+        self.rawboost_algo, self.rawboost_args, self.seed, self.nstep = rawboost_algo, rawboost_args, seed, 0
         self.dropout_masks = dropout_masks      # None: draw masks on the device (normal training); {}: no dropout; dict: injected keep-masks
         self.be = model.backend
         self.fe = model.ssl_model.model
@@ -31,6 +33,11 @@ class OcTrainer:
     def step(self, wav, labels):
         """wav f32 [B,L] cuda, labels i64 [B] cuda.  Returns device tensors (loss_c, loss_d); no host sync."""
         be = self.be
+        if self.rawboost_algo:          # on-GPU RawBoost (data_utils_SSL.py:111-173; the call the reference leaves commented at oc_training.py:221)
+            from .RawBoost import rawboost_batch_device
+            from .oc_training import rawboost_args
+            wav = rawboost_batch_device(wav, self.rawboost_args or rawboost_args(), self.rawboost_algo, seed=self.seed, step=self.nstep)
+        self.nstep += 1
         if self.train_frontend:
             return self._step_finetune(wav, labels)
         feats = self.model.ssl_model.model.forward(wav, out_dtype=torch.float32)

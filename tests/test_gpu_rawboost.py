@@ -123,3 +123,72 @@ def test_philox_fill_statistics_and_determinism():
     assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1.0) < 5e-3
     u = ops.philox_fill((1 << 20,), torch.float64, seed=1, stream_id=0, normal=False)
     assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 2e-3
+
+
+def test_device_filter_design_matches_host_design():
+    """occ_notch_coeffs (device, batched) == occ_notch_coeffs_host (pinned against the reference's genNotchCoeffs)."""
+    import ctypes
+    from occm_amd import ops
+    from occm_amd._lib import check, lib, ptr, stream_ptr
+    rs = np.random.RandomState(4)
+    nf, nb = 37, 5
+    fc, bw = rs.uniform(20, 8000, (nf, nb)), rs.uniform(100, 1000, (nf, nb))
+    c = rs.uniform(10, 100, (nf, nb)).astype(np.int32)
+    G = rs.uniform(-20, 0, nf)
+    dev = lambda t: torch.from_numpy(np.ascontiguousarray(t)).cuda()
+    coef, nt = torch.empty(nf, 512, dtype=torch.float64, device="cuda"), torch.empty(nf, dtype=torch.int32, device="cuda")
+    fc_d, bw_d, c_d, g_d = dev(fc), dev(bw), dev(c), dev(G)          # keep the device copies alive across the launch
+    check(lib().occ_notch_coeffs(ptr(fc_d), ptr(bw_d), ptr(c_d), ptr(g_d), nf, nb, 16000.0, ptr(coef), ptr(nt), 512, stream_ptr()), "occ_notch_coeffs")
+    for f in range(nf):
+        ref, rn = ops.notch_coeffs_host([(fc[f, i], bw[f, i], int(c[f, i])) for i in range(nb)], G[f], 16000, 512)
+        assert int(nt[f]) == rn
+        np.testing.assert_allclose(coef[f].cpu().numpy(), ref, rtol=1e-9, atol=1e-13)
+
+
+def test_device_isd_touches_exactly_n_random_positions():
+    from occm_amd._lib import check, lib, ptr, stream_ptr
+    B, Lx = 6, 64600
+    x = torch.from_numpy(np.stack([synth_wave(200 + b, Lx) for b in range(B)])).double().cuda() + 0.5
+    y = x.clone()
+    n_host = np.array([0, 1, 17, 3230, 6460, 64600], dtype=np.int32)
+    n = torch.from_numpy(n_host).cuda()
+    thr, cnt = torch.empty(B, dtype=torch.int32, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda")
+    check(lib().occ_rawboost_isd_device(ptr(y), ptr(n), ptr(thr), ptr(cnt), B, Lx, 2.0, 11, 3, stream_ptr()), "occ_rawboost_isd_device")
+    changed = (y != x)
+    ratio = ((y / x) - 1.0).abs()
+    assert float(ratio.max()) <= 2.0 + 1e-12                      # |g_sd * (2u1-1)(2u2-1)| <= g_sd
+    for b in range(B):
+        k = int(cnt[b])
+        assert n_host[b] <= k <= n_host[b] + 2, (b, k, n_host[b])   # ties with the threshold key can add a position
+        assert int(changed[b].sum()) <= k
+    # positions are spread uniformly: mean index of the touched samples is near the middle
+    idx = torch.nonzero(changed[4]).float().mean().item()
+    assert abs(idx / Lx - 0.5) < 0.03
+    y2 = x.clone()
+    check(lib().occ_rawboost_isd_device(ptr(y2), ptr(n), ptr(thr), None, B, Lx, 2.0, 11, 3, stream_ptr()), "occ_rawboost_isd_device")
+    assert torch.equal(y, y2)                                     # counter-based: same (seed, stream) -> same augmentation
+
+
+@pytest.mark.parametrize("algo", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_device_mode_pipeline_properties(algo):
+    """Device-RNG mode draws a different random stream than the reference, so it is checked through the invariants every
+    RawBoost output satisfies plus agreement of its deterministic parts with the oracle."""
+    from occm_amd.RawBoost import rawboost_batch_device
+    B, Lx = 4, 64000
+    x = torch.from_numpy(np.stack([synth_wave(300 + b, Lx) for b in range(B)])).cuda()
+    y = rawboost_batch_device(x, _args(), algo, seed=5, step=7)
+    assert y.shape == x.shape and y.dtype == torch.float32 and bool(torch.isfinite(y).all())
+    y2 = rawboost_batch_device(x, _args(), algo, seed=5, step=7)
+    assert torch.equal(y, y2)
+    y3 = rawboost_batch_device(x, _args(), algo, seed=5, step=8)
+    assert not torch.equal(y, y3)
+    if algo in (1, 5, 8):
+        assert float(y.abs().max()) <= 1.0 + 1e-6                # LnL / ISD end with the peak>1 normalisation
+    if algo == 1:
+        assert float(y.double().mean(dim=1).abs().max()) < 1e-6   # mean removed
+    if algo == 2:
+        frac = (y != x).float().mean(dim=1)
+        assert float(frac.max()) <= 0.1 + 1e-3                    # at most P = 10 % of the samples are touched
+    if algo == 3:
+        snr = 10 * torch.log10((x.double() ** 2).sum(1) / ((y.double() - x.double()) ** 2).sum(1))
+        assert float(snr.min()) > 10 - 0.01 and float(snr.max()) < 40 + 0.01
