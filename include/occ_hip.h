@@ -238,6 +238,25 @@ typedef struct occ_readout_grads {
 int occ_readout_fwd(const occ_readout_desc* d, void* stream);
 int occ_readout_bwd(const occ_readout_desc* d, const occ_readout_grads* g, void* stream);
 
+/* ---------------------------------------------------- SE-ResNet34 back-end pieces (models/senet.py:13-156), f32 channels-last ---- */
+/* nn.MaxPool2d(3, stride 2, padding 1): x [B,H,W,C] -> y (rows through y_map) + argmax taps; bwd scatter-adds into a pre-zeroed dx.   */
+int occ_maxpool3s2_fwd(const float* x, float* y, const occ_rowmap* y_map, uint8_t* idx, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+int occ_maxpool3s2_bwd(const float* dy, const occ_rowmap* dy_map, const uint8_t* idx, float* dx, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+/* out[b,c] = alpha * sum_r x[b,r,c] (AdaptiveAvgPool2d(1) of SELayer / the network head); x rows (b*R + r) through a row map.         */
+int occ_batch_colsum(const float* x, const occ_rowmap* x_map, int64_t B, int64_t R, int64_t C, float alpha, float* out, void* stream);
+/* SELayer.fc (senet.py:17-22): g = sigmoid(W2 relu(W1 s)); z [B,Cr] saved; bwd accumulates dW1, dW2 and returns ds.                   */
+int occ_se_gate_fwd(const float* s, const float* W1, const float* W2, int64_t B, int64_t C, int64_t Cr, float* z, float* g, void* stream);
+int occ_se_gate_bwd(const float* s, const float* z, const float* g, const float* dg, const float* W1, const float* W2, int64_t B, int64_t C,
+                    int64_t Cr, float* dW1, float* dW2, float* ds, void* stream);
+/* SEBasicBlock tail (senet.py:53-61): out = relu(y*gate[b,c] + res); bwd gives dy, dres (write or accumulate) and dgate (accumulated). */
+int occ_se_scale_add_relu(const float* y, const float* gate, const float* res, const occ_rowmap* res_map, float* out, const occ_rowmap* out_map,
+                          int64_t B, int64_t R, int64_t C, void* stream);
+int occ_se_scale_add_relu_bwd(const float* dout, const occ_rowmap* dout_map, const float* out, const occ_rowmap* out_map, const float* y,
+                              const float* gate, float* dy, float* dres, const occ_rowmap* dres_map, int dres_accumulate, float* dgate, int64_t B,
+                              int64_t R, int64_t C, void* stream);
+/* x[b,r,c] += v[b,c] (gradient of a global average pool).                                                                     */
+int occ_add_batch_vec(float* x, const occ_rowmap* x_map, const float* v, int64_t B, int64_t R, int64_t C, void* stream);
+
 /* ------------------------------------------------------------- front-end row kernels ------- */
 /* y = LayerNorm(x) * gamma + beta, optional GELU, over rows of width C (C % 64 == 0, C <= 8192).
  * fairseq LayerNorm / Fp32LayerNorm + GELU of the conv blocks and transformer layers.            */

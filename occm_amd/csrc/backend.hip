@@ -778,6 +778,157 @@ __global__ __launch_bounds__(BT) void readout_bwd_kernel(const ReadoutBP q) {
     }
 }
 
+// ----------------------------------------------------------------- SE-ResNet34 pieces (models/senet.py) --
+// MaxPool2d(3, stride 2, padding 1) on channels-last x [B,H,W,C] -> y [B,Ho,Wo,C] (through a row map: the next conv's
+// zero-bordered input), idx = argmax tap 0..8 (255: window empty).                                   senet.py:76, 124
+__global__ void maxpool3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, RowMapI ymap, unsigned char* __restrict__ idx, int B, int H, int W,
+                                      int C, int Ho, int Wo) {
+    const long long n = (long long)B * Ho * Wo * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c = (int)(r % C); r /= C;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho); const int b = (int)(r / Ho);
+        float best = -3.4e38f; int bi = 255;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int h = 2 * ho - 1 + dh, w = 2 * wo - 1 + dw;
+                if (h >= 0 && h < H && w >= 0 && w < W) {
+                    const float v = x[(((size_t)b * H + h) * W + w) * C + c];
+                    if (v > best) { best = v; bi = dh * 3 + dw; }
+                }
+            }
+        y[row_off(ymap, i / C) + c] = best;
+        idx[i] = (unsigned char)bi;
+    }
+}
+// dx (pre-zeroed, [B,H,W,C]) += scatter of dy (through a row map) to the argmax positions
+__global__ void maxpool3s2_bwd_kernel(const float* __restrict__ dy, RowMapI dymap, const unsigned char* __restrict__ idx, float* __restrict__ dx, int B, int H,
+                                      int W, int C, int Ho, int Wo) {
+    const long long n = (long long)B * Ho * Wo * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c = (int)(r % C); r /= C;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho); const int b = (int)(r / Ho);
+        const int bi = idx[i];
+        if (bi == 255) continue;
+        const int h = 2 * ho - 1 + bi / 3, w = 2 * wo - 1 + bi % 3;
+        atomicAdd(dx + (((size_t)b * H + h) * W + w) * C + c, dy[row_off(dymap, i / C) + c]);
+    }
+}
+// out[b,c] = alpha * sum_r x[b, r, c]  (x rows through a row map whose batch level is b): global average pools
+__global__ __launch_bounds__(BT) void batch_colsum_kernel(const float* __restrict__ x, RowMapI xmap, int R, int C, float alpha, float* __restrict__ out) {
+    __shared__ float red[BT];
+    const int b = blockIdx.x;
+    const int c = threadIdx.x % C, part = threadIdx.x / C, nparts = BT / C;
+    float s = 0.f;
+    for (int r = part; r < R; r += nparts) s += x[row_off(xmap, (long long)b * R + r) + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        for (int k = 1; k < nparts; ++k) s += red[threadIdx.x + k * C];
+        out[(size_t)b * C + c] = s * alpha;
+    }
+}
+// SELayer gate (senet.py:13-28): g = sigmoid(W2 relu(W1 s)), s [B,C], W1 [Cr,C], W2 [C,Cr] (no biases); z [B,Cr] is kept.
+__global__ __launch_bounds__(BT) void se_gate_fwd_kernel(const float* __restrict__ s, const float* __restrict__ W1, const float* __restrict__ W2, int C, int Cr,
+                                                         float* __restrict__ z, float* __restrict__ g) {
+    extern __shared__ float sm[];            // s [C] + z [Cr]
+    float* ss = sm; float* zs = sm + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += BT) ss[c] = s[(size_t)b * C + c];
+    __syncthreads();
+    for (int j = threadIdx.x; j < Cr; j += BT) {
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(W1[j * C + c], ss[c], a);
+        a = a > 0.f ? a : 0.f;
+        zs[j] = a; z[(size_t)b * Cr + j] = a;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += BT) {
+        float a = 0.f;
+        for (int j = 0; j < Cr; ++j) a = fmaf(W2[c * Cr + j], zs[j], a);
+        g[(size_t)b * C + c] = 1.0f / (1.0f + expf(-a));
+    }
+}
+// given dg [B,C]: dW2 += (dg*g*(1-g)) z^T ; dz = W2^T (..) masked by z>0 ; dW1 += dz s^T ; ds = W1^T dz
+__global__ __launch_bounds__(BT) void se_gate_bwd_kernel(const float* __restrict__ s, const float* __restrict__ z, const float* __restrict__ g,
+                                                         const float* __restrict__ dg, const float* __restrict__ W1, const float* __restrict__ W2, int C, int Cr,
+                                                         float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ ds) {
+    extern __shared__ float sm[];            // da [C] + dz [Cr] + s [C] + z [Cr]
+    float* da = sm; float* dz = da + C; float* ss = dz + Cr; float* zs = ss + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += BT) {
+        const float gv = g[(size_t)b * C + c];
+        da[c] = dg[(size_t)b * C + c] * gv * (1.f - gv);
+        ss[c] = s[(size_t)b * C + c];
+    }
+    for (int j = threadIdx.x; j < Cr; j += BT) zs[j] = z[(size_t)b * Cr + j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * Cr; i += BT) atomicAdd(dW2 + i, da[i / Cr] * zs[i % Cr]);
+    for (int j = threadIdx.x; j < Cr; j += BT) {
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(W2[c * Cr + j], da[c], a);
+        dz[j] = zs[j] > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cr * C; i += BT) atomicAdd(dW1 + i, dz[i / C] * ss[i % C]);
+    for (int c = threadIdx.x; c < C; c += BT) {
+        float a = 0.f;
+        for (int j = 0; j < Cr; ++j) a = fmaf(W1[j * C + c], dz[j], a);
+        ds[(size_t)b * C + c] = a;
+    }
+}
+// out = relu(y * gate[b,c] + res)   (SEBasicBlock tail, senet.py:53-61); rows = B*R, batch b = row / R
+__global__ void se_scale_add_relu_kernel(const float* __restrict__ y, const float* __restrict__ gate, const float* __restrict__ res, RowMapI rmap,
+                                         float* __restrict__ out, RowMapI omap, long long rows, int R, int C) {
+    const long long n = rows * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C; const int c = (int)(i - r * C);
+        const float v = y[i] * gate[(r / R) * C + c] + res[row_off(rmap, r) + c];
+        out[row_off(omap, r) + c] = v > 0.f ? v : 0.f;
+    }
+}
+// dpre = dout * (out > 0); dres = dpre (through a row map, accumulate or write); dy = dpre * gate; dgate[b,c] += sum dpre*y
+__global__ __launch_bounds__(BT) void se_scale_add_relu_bwd_kernel(const float* __restrict__ dout, RowMapI domap, const float* __restrict__ out, RowMapI omap,
+                                                                   const float* __restrict__ y, const float* __restrict__ gate, float* __restrict__ dy,
+                                                                   float* __restrict__ dres, RowMapI drmap, int dres_accumulate, float* __restrict__ dgate,
+                                                                   int R, int C) {
+    __shared__ float red[BT];
+    const int b = blockIdx.y;
+    const int c = threadIdx.x % C, part = threadIdx.x / C, nparts = BT / C;
+    const int chunk = (R + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * chunk, r1 = r0 + chunk < R ? r0 + chunk : R;
+    float acc = 0.f;
+    for (int rr = r0 + part; rr < r1; rr += nparts) {
+        const long long r = (long long)b * R + rr;
+        const float o = out[row_off(omap, r) + c];
+        const float dp = o > 0.f ? dout[row_off(domap, r) + c] : 0.f;
+        const float yv = y[r * C + c];
+        dy[r * C + c] = dp * gate[(size_t)b * C + c];
+        float* dr = dres + row_off(drmap, r) + c;
+        *dr = dres_accumulate ? *dr + dp : dp;
+        acc += dp * yv;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        for (int k = 1; k < nparts; ++k) acc += red[threadIdx.x + k * C];
+        atomicAdd(dgate + (size_t)b * C + c, acc);
+    }
+}
+// x[b, r, c] += v[b, c]   (gradient of a global average pool, v already divided by R)
+__global__ void add_batch_vec_kernel(float* __restrict__ x, RowMapI xmap, const float* __restrict__ v, long long rows, int R, int C) {
+    const long long n = rows * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C; const int c = (int)(i - r * C);
+        x[row_off(xmap, r) + c] += v[(r / R) * C + c];
+    }
+}
+
 int grid_for(long long n, int per = BT) { long long g = occ_cdiv(n, per); return (int)(g < 8192 ? (g < 1 ? 1 : g) : 8192); }
 
 }  // namespace
@@ -1026,6 +1177,69 @@ int occ_readout_bwd(const occ_readout_desc* d, const occ_readout_grads* g, void*
     q.dW = g->d_out_w; q.dbias = g->d_out_b;
     hipLaunchKernelGGL(readout_bwd_kernel, dim3((unsigned)d->B), dim3(BT), 5 * d->Dg * sizeof(float), (hipStream_t)stream, q);
     OCC_LAUNCH_CHECK("occ_readout_bwd");
+    return OCC_OK;
+}
+
+int occ_maxpool3s2_fwd(const float* x, float* y, const occ_rowmap* y_map, uint8_t* idx, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+    OCC_CHECK_ARG(x && y && y_map && idx && B >= 1 && H >= 1 && W >= 1 && C >= 1 && y_map->rows_per_batch >= 1, "occ_maxpool3s2_fwd: bad argument");
+    const int Ho = (int)((H + 2 - 3) / 2 + 1), Wo = (int)((W + 2 - 3) / 2 + 1);
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(grid_for(B * Ho * Wo * C)), dim3(BT), 0, (hipStream_t)stream, x, y, to_rowmap(*y_map), idx, (int)B, (int)H, (int)W,
+                       (int)C, Ho, Wo);
+    OCC_LAUNCH_CHECK("occ_maxpool3s2_fwd");
+    return OCC_OK;
+}
+int occ_maxpool3s2_bwd(const float* dy, const occ_rowmap* dy_map, const uint8_t* idx, float* dx, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+    OCC_CHECK_ARG(dy && dy_map && idx && dx && B >= 1 && H >= 1 && W >= 1 && C >= 1 && dy_map->rows_per_batch >= 1, "occ_maxpool3s2_bwd: bad argument");
+    const int Ho = (int)((H + 2 - 3) / 2 + 1), Wo = (int)((W + 2 - 3) / 2 + 1);
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(grid_for(B * Ho * Wo * C)), dim3(BT), 0, (hipStream_t)stream, dy, to_rowmap(*dy_map), idx, dx, (int)B, (int)H, (int)W,
+                       (int)C, Ho, Wo);
+    OCC_LAUNCH_CHECK("occ_maxpool3s2_bwd");
+    return OCC_OK;
+}
+int occ_batch_colsum(const float* x, const occ_rowmap* x_map, int64_t B, int64_t R, int64_t C, float alpha, float* out, void* stream) {
+    OCC_CHECK_ARG(x && x_map && out && B >= 1 && R >= 1 && C >= 1 && C <= 256 && 256 % C == 0 && x_map->rows_per_batch >= 1, "occ_batch_colsum: bad argument");
+    hipLaunchKernelGGL(batch_colsum_kernel, dim3((unsigned)B), dim3(BT), 0, (hipStream_t)stream, x, to_rowmap(*x_map), (int)R, (int)C, alpha, out);
+    OCC_LAUNCH_CHECK("occ_batch_colsum");
+    return OCC_OK;
+}
+int occ_se_gate_fwd(const float* s, const float* W1, const float* W2, int64_t B, int64_t C, int64_t Cr, float* z, float* g, void* stream) {
+    OCC_CHECK_ARG(s && W1 && W2 && z && g && B >= 1 && C >= 1 && Cr >= 1, "occ_se_gate_fwd: bad argument");
+    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3((unsigned)B), dim3(BT), (C + Cr) * sizeof(float), (hipStream_t)stream, s, W1, W2, (int)C, (int)Cr, z, g);
+    OCC_LAUNCH_CHECK("occ_se_gate_fwd");
+    return OCC_OK;
+}
+int occ_se_gate_bwd(const float* s, const float* z, const float* g, const float* dg, const float* W1, const float* W2, int64_t B, int64_t C, int64_t Cr,
+                    float* dW1, float* dW2, float* ds, void* stream) {
+    OCC_CHECK_ARG(s && z && g && dg && W1 && W2 && dW1 && dW2 && ds && B >= 1 && C >= 1 && Cr >= 1, "occ_se_gate_bwd: bad argument");
+    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3((unsigned)B), dim3(BT), 2 * (C + Cr) * sizeof(float), (hipStream_t)stream, s, z, g, dg, W1, W2, (int)C, (int)Cr, dW1,
+                       dW2, ds);
+    OCC_LAUNCH_CHECK("occ_se_gate_bwd");
+    return OCC_OK;
+}
+int occ_se_scale_add_relu(const float* y, const float* gate, const float* res, const occ_rowmap* res_map, float* out, const occ_rowmap* out_map, int64_t B,
+                          int64_t R, int64_t C, void* stream) {
+    OCC_CHECK_ARG(y && gate && res && res_map && out && out_map && B >= 1 && R >= 1 && C >= 1, "occ_se_scale_add_relu: bad argument");
+    hipLaunchKernelGGL(se_scale_add_relu_kernel, dim3(grid_for(B * R * C)), dim3(BT), 0, (hipStream_t)stream, y, gate, res, to_rowmap(*res_map), out,
+                       to_rowmap(*out_map), (long long)(B * R), (int)R, (int)C);
+    OCC_LAUNCH_CHECK("occ_se_scale_add_relu");
+    return OCC_OK;
+}
+int occ_se_scale_add_relu_bwd(const float* dout, const occ_rowmap* dout_map, const float* out, const occ_rowmap* out_map, const float* y, const float* gate,
+                              float* dy, float* dres, const occ_rowmap* dres_map, int dres_accumulate, float* dgate, int64_t B, int64_t R, int64_t C,
+                              void* stream) {
+    OCC_CHECK_ARG(dout && dout_map && out && out_map && y && gate && dy && dres && dres_map && dgate, "occ_se_scale_add_relu_bwd: null pointer");
+    OCC_CHECK_ARG(B >= 1 && B < 65536 && R >= 1 && C >= 1 && C <= 256 && 256 % C == 0, "occ_se_scale_add_relu_bwd: bad shape");
+    long long gx = occ_cdiv(R, 64);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(se_scale_add_relu_bwd_kernel, dim3((unsigned)gx, (unsigned)B), dim3(BT), 0, (hipStream_t)stream, dout, to_rowmap(*dout_map), out,
+                       to_rowmap(*out_map), y, gate, dy, dres, to_rowmap(*dres_map), dres_accumulate, dgate, (int)R, (int)C);
+    OCC_LAUNCH_CHECK("occ_se_scale_add_relu_bwd");
+    return OCC_OK;
+}
+int occ_add_batch_vec(float* x, const occ_rowmap* x_map, const float* v, int64_t B, int64_t R, int64_t C, void* stream) {
+    OCC_CHECK_ARG(x && x_map && v && B >= 1 && R >= 1 && C >= 1, "occ_add_batch_vec: bad argument");
+    hipLaunchKernelGGL(add_batch_vec_kernel, dim3(grid_for(B * R * C)), dim3(BT), 0, (hipStream_t)stream, x, to_rowmap(*x_map), v, (long long)(B * R), (int)R, (int)C);
+    OCC_LAUNCH_CHECK("occ_add_batch_vec");
     return OCC_OK;
 }
 

@@ -1,0 +1,143 @@
+"""HIP SE-ResNet34 back-end (C ABI) vs the reference's own outputs (tests/golden/senet.npz, produced by models/senet.py
+se_resnet34 in eval and train mode) and, for gradients, vs autograd through the torch-CPU oracle.
+Tolerance: 1e-3 (north-star fp32 bar) on outputs; gradients 2e-3 of the tensor's max with the AASIST absolute floor."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+GS = golden("senet.npz")
+CASES = [("lfcc", (4, 1, 266, 13), 7), ("ssl", (2, 1, 199, 1024), 8)]
+GRAD_FLOOR = 5e-4
+
+
+def _params():
+    from oracle import senet_ref
+    from oracle.fill import fill_like
+    return fill_like(senet_ref.param_shapes(), seed=1)
+
+
+def _x(shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+# ------------------------------------------------------------------------------- kernel level ---
+def test_maxpool_se_kernels():
+    import ctypes
+    import torch.nn.functional as F
+    from occm_amd import backend_ops as K
+    from occm_amd._lib import check, lib, ptr, stream_ptr
+    B, H, W, C = 2, 13, 9, 16
+    x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(0))
+    xc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, C).cuda(); idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8).cuda()
+    m = K.rowmap(B * Ho * Wo, 0, C)
+    check(lib().occ_maxpool3s2_fwd(ptr(xc), ptr(y), ctypes.byref(m), ptr(idx), B, H, W, C, stream_ptr()), "maxpool")
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, stride=2, padding=1)
+    torch.testing.assert_close(y.cpu().permute(0, 3, 1, 2), ref.detach(), rtol=0, atol=0)
+    dy = torch.randn(B, C, Ho, Wo, generator=torch.Generator().manual_seed(1))
+    ref.backward(dy)
+    dyc = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = torch.zeros(B, H, W, C).cuda()
+    check(lib().occ_maxpool3s2_bwd(ptr(dyc), ctypes.byref(m), ptr(idx), ptr(dx), B, H, W, C, stream_ptr()), "maxpool bwd")
+    torch.testing.assert_close(dx.cpu().permute(0, 3, 1, 2), xr.grad, rtol=1e-6, atol=1e-6)
+
+    # SE gate forward / backward against autograd
+    Cc, Cr = 64, 4
+    s = torch.randn(B, Cc, generator=torch.Generator().manual_seed(2)).requires_grad_(True)
+    W1 = (torch.randn(Cr, Cc, generator=torch.Generator().manual_seed(3)) * 0.2).requires_grad_(True)
+    W2 = (torch.randn(Cc, Cr, generator=torch.Generator().manual_seed(4)) * 0.5).requires_grad_(True)
+    g_ref = torch.sigmoid(F.linear(F.relu(F.linear(s, W1)), W2))
+    dg = torch.randn(B, Cc, generator=torch.Generator().manual_seed(5))
+    g_ref.backward(dg)
+    sd, w1d, w2d = s.detach().cuda(), W1.detach().cuda(), W2.detach().cuda()
+    z, g = torch.empty(B, Cr).cuda(), torch.empty(B, Cc).cuda()
+    check(lib().occ_se_gate_fwd(ptr(sd), ptr(w1d), ptr(w2d), B, Cc, Cr, ptr(z), ptr(g), stream_ptr()), "se fwd")
+    torch.testing.assert_close(g.cpu(), g_ref.detach(), rtol=1e-5, atol=1e-6)
+    dW1, dW2, ds = torch.zeros(Cr, Cc).cuda(), torch.zeros(Cc, Cr).cuda(), torch.empty(B, Cc).cuda()
+    dgd = dg.cuda()
+    check(lib().occ_se_gate_bwd(ptr(sd), ptr(z), ptr(g), ptr(dgd), ptr(w1d), ptr(w2d), B, Cc, Cr, ptr(dW1), ptr(dW2), ptr(ds), stream_ptr()), "se bwd")
+    torch.testing.assert_close(ds.cpu(), s.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(dW1.cpu(), W1.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(dW2.cpu(), W2.grad, rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------- whole network ---
+@pytest.mark.parametrize("tag,shape,seed", CASES)
+def test_senet_matches_reference_outputs(tag, shape, seed):
+    from occm_amd.models.senet import se_resnet34
+    net = se_resnet34(state_dict=_params())
+    x = _x(shape, seed).cuda()
+    net.eval()
+    com, des = net(x)
+    np.testing.assert_allclose(com.cpu().numpy(), GS["eval_com_" + tag], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(des.cpu().numpy(), GS["eval_des_" + tag], rtol=1e-3, atol=1e-3)
+    net.train()
+    com, des = net(x)
+    np.testing.assert_allclose(com.cpu().numpy(), GS["train_com_" + tag], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(des.cpu().numpy(), GS["train_des_" + tag], rtol=1e-3, atol=1e-3)
+
+
+def test_senet_state_dict_round_trip_and_running_stats():
+    from oracle import senet_ref
+    from occm_amd.models.senet import se_resnet34
+    p = _params()
+    net = se_resnet34(state_dict=p)
+    sd = net.state_dict()
+    assert set(sd) == set(senet_ref.param_shapes())
+    for k, v in p.items():
+        torch.testing.assert_close(sd[k].cpu().to(v.dtype).reshape(v.shape), v, rtol=0, atol=0)
+    x = _x((3, 1, 64, 40), 3)
+    net.train()
+    net(x.cuda())
+    q = {k: v.clone() for k, v in p.items()}
+    with torch.no_grad():
+        senet_ref.senet34_forward(x, q, train=True)          # the oracle's _bn moves q's running stats in place
+    sd = net.state_dict()
+    for k in ("bn1", "layer2.0.downsample.1", "layer4.2.bn2"):
+        torch.testing.assert_close(sd[k + ".running_mean"].cpu(), q[k + ".running_mean"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(sd[k + ".running_var"].cpu(), q[k + ".running_var"], rtol=1e-3, atol=1e-4)
+        assert int(sd[k + ".num_batches_tracked"]) == int(q[k + ".num_batches_tracked"])
+
+
+@pytest.mark.parametrize("shape,seed", [((3, 1, 70, 45), 11), ((2, 1, 199, 1024), 8)])
+def test_senet_gradients_match_oracle_autograd(shape, seed):
+    from oracle import senet_ref
+    from occm_amd.models.senet import se_resnet34
+    p = _params()
+    x = _x(shape, seed)
+    B = shape[0]
+    dcom = torch.randn(B, 128, generator=torch.Generator().manual_seed(20))
+    ddes = torch.randn(B, 2, generator=torch.Generator().manual_seed(21))
+    q = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in p.items()}
+    com, des = senet_ref.senet34_forward(x, q, train=True)
+    ((com * dcom).sum() + (des * ddes).sum()).backward()
+
+    net = se_resnet34(state_dict=p)
+    net.train()
+    com_g, des_g = net(x.cuda())
+    torch.testing.assert_close(com_g.cpu(), com.detach(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(des_g.cpu(), des.detach(), rtol=1e-3, atol=1e-3)
+    net.backend.zero_grad()
+    net.backward(dcom.cuda(), ddes.cuda())
+    grads = net.backend.grad_dict()
+    bad = []
+    for k, v in q.items():
+        if not (torch.is_tensor(v) and v.requires_grad):
+            continue
+        ref = v.grad if v.grad is not None else torch.zeros_like(v)
+        got = grads[k].cpu()
+        tol = max(2e-3 * float(ref.abs().max()), GRAD_FLOOR)
+        err = float((got - ref).abs().max())
+        if err > tol:
+            bad.append((k, err, tol, float(ref.abs().max())))
+    assert not bad, bad[:10]
+    # a second backward accumulates (the trainer relies on zero_grad between steps)
+    net(x.cuda())
+    net.backward(dcom.cuda(), ddes.cuda())
+    g2 = net.backend.grad_dict()
+    torch.testing.assert_close(g2["layer3.0.conv1.weight"], 2 * grads["layer3.0.conv1.weight"], rtol=1e-3, atol=1e-5)
