@@ -256,6 +256,9 @@ int occ_se_scale_add_relu_bwd(const float* dout, const occ_rowmap* dout_map, con
                               int64_t R, int64_t C, void* stream);
 /* x[b,r,c] += v[b,c] (gradient of a global average pool).                                                                     */
 int occ_add_batch_vec(float* x, const occ_rowmap* x_map, const float* v, int64_t B, int64_t R, int64_t C, void* stream);
+/* Input gradient of the stem conv (senet.py:73: Conv2d(1,16,7,stride 2,padding 3)): dy [B,Ho,Wo,16], w [16][7][7][4] (input channel padded
+ * to 4, as the forward implicit GEMM uses it) -> dx [B,H,W]; needed only when the front-end under the SE-ResNet is fine-tuned.            */
+int occ_conv7s2_dgrad_c1(const float* dy, const float* w, float* dx, int64_t B, int64_t H, int64_t W, void* stream);
 
 /* ------------------------------------------------------------- front-end row kernels ------- */
 /* y = LayerNorm(x) * gamma + beta, optional GELU, over rows of width C (C % 64 == 0, C <= 8192).

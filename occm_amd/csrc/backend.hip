@@ -929,6 +929,37 @@ __global__ void add_batch_vec_kernel(float* __restrict__ x, RowMapI xmap, const 
     }
 }
 
+// Input gradient of the SE-ResNet stem conv (1 input channel, 16 output channels, 7x7, stride 2, padding 3; senet.py:73):
+// dx[b,h,w] = sum_{kh,kw,co} dy[b,(h+3-kh)/2,(w+3-kw)/2,co] * w[co,kh,kw] over the taps with even offsets that land inside dy.
+// w is the engine's [16][7][7][4] layout (input channel padded to 4); one thread per input pixel, <= 16 taps x 16 channels.
+__global__ __launch_bounds__(BT) void conv7s2_dgrad_c1_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int B, int H, int W,
+                                                              int Ho, int Wo) {
+    __shared__ float wl[49 * 16];               // [kh][kw][co]
+    for (int i = threadIdx.x; i < 49 * 16; i += BT) { const int co = i & 15, t = i >> 4; wl[i] = w[(co * 49 + t) * 4]; }
+    __syncthreads();
+    const long long n = (long long)B * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W); const long long r = i / W; const int h = (int)(r % H); const int b = (int)(r / H);
+        float acc = 0.f;
+        for (int kh = (h + 3) & 1; kh < 7; kh += 2) {
+            const int ho = (h + 3 - kh) >> 1;
+            if (h + 3 - kh < 0 || ho >= Ho) continue;
+            for (int kw = (x + 3) & 1; kw < 7; kw += 2) {
+                const int wo = (x + 3 - kw) >> 1;
+                if (x + 3 - kw < 0 || wo >= Wo) continue;
+                const float4* d = reinterpret_cast<const float4*>(dy + (((size_t)b * Ho + ho) * Wo + wo) * 16);
+                const float* ww = wl + (kh * 7 + kw) * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = d[q];
+                    acc = fmaf(v.x, ww[4 * q], acc); acc = fmaf(v.y, ww[4 * q + 1], acc); acc = fmaf(v.z, ww[4 * q + 2], acc); acc = fmaf(v.w, ww[4 * q + 3], acc);
+                }
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
 int grid_for(long long n, int per = BT) { long long g = occ_cdiv(n, per); return (int)(g < 8192 ? (g < 1 ? 1 : g) : 8192); }
 
 }  // namespace
@@ -1240,6 +1271,13 @@ int occ_add_batch_vec(float* x, const occ_rowmap* x_map, const float* v, int64_t
     OCC_CHECK_ARG(x && x_map && v && B >= 1 && R >= 1 && C >= 1, "occ_add_batch_vec: bad argument");
     hipLaunchKernelGGL(add_batch_vec_kernel, dim3(grid_for(B * R * C)), dim3(BT), 0, (hipStream_t)stream, x, to_rowmap(*x_map), v, (long long)(B * R), (int)R, (int)C);
     OCC_LAUNCH_CHECK("occ_add_batch_vec");
+    return OCC_OK;
+}
+int occ_conv7s2_dgrad_c1(const float* dy, const float* w, float* dx, int64_t B, int64_t H, int64_t W, void* stream) {
+    OCC_CHECK_ARG(dy && w && dx && B >= 1 && H >= 1 && W >= 1 && (((uintptr_t)dy) & 15) == 0, "occ_conv7s2_dgrad_c1: bad argument");
+    const int Ho = (int)((H + 6 - 7) / 2 + 1), Wo = (int)((W + 6 - 7) / 2 + 1);
+    hipLaunchKernelGGL(conv7s2_dgrad_c1_kernel, dim3(grid_for(B * H * W)), dim3(BT), 0, (hipStream_t)stream, dy, w, dx, (int)B, (int)H, (int)W, Ho, Wo);
+    OCC_LAUNCH_CHECK("occ_conv7s2_dgrad_c1");
     return OCC_OK;
 }
 

@@ -178,9 +178,12 @@ class SeResNet34Backend:
         return g
 
     # ======================================================================================= forward ==
-    def forward(self, x, train=False):
-        """x f32 [B,1,T,D] -> (com [B,128], des [B,2])."""
+    def forward(self, x, train=False, masks=None):
+        """x f32 [B,1,T,D] (or [B,T,D] front-end features) -> (com [B,128], des [B,2]).  ``masks`` is accepted for interface parity with the
+        AASIST engine and ignored: the network has no dropout."""
         x = x.to(self.device, torch.float32)
+        if x.dim() == 3:
+            x = x.unsqueeze(1)
         if x.dim() != 4 or x.shape[1] != 1:
             raise OccError("se_resnet34 expects [B,1,T,D]")
         B, _, H0, W0 = x.shape
@@ -275,7 +278,8 @@ class SeResNet34Backend:
         K.copy_strided(w, out, 2 * 3 * ci + 2 * ci, (ci, 3, 3, co), (1, -3 * ci, -ci, 9 * ci))
         return out
 
-    def backward(self, dcom, ddes):
+    def backward(self, dcom, ddes, want_dfeats=False):
+        """Accumulates parameter gradients into G; with want_dfeats returns d loss / d input [B,T,D]."""
         c = self.ctx
         if c is None:
             raise OccError("backward() needs a preceding forward(train=True)")
@@ -374,6 +378,11 @@ class SeResNet34Backend:
         Wp0 = W0 + 6
         K.gemm_tn(R0, 16, 196, dc1, rowmap(R0, 0, 16), geo["X0"], rowmap(H1 * W1, (H0 + 6) * Wp0 * 4, 8, W1, 2 * Wp0 * 4), g["conv1.weight"], 196, b_seg=(7, 28, Wp0 * 4))
         self.ctx = None
+        if want_dfeats:
+            dx = self._e(B, H0, W0)
+            check(lib().occ_conv7s2_dgrad_c1(ptr(dc1), ptr(p["conv1.weight"]), ptr(dx), B, H0, W0, stream_ptr()), "occ_conv7s2_dgrad_c1")
+            return dx
+        return None
 
     def _dgrad_s2(self, bg, B, w1, D1, dX):
         """Input gradient of a 3x3 stride-2 pad-1 conv as four parity-class GEMMs over D1 [B,Ho+1,Wo+1,pl] (zero last row / column)."""
@@ -446,8 +455,8 @@ class _SeResNet(torch.nn.Module):
     def forward(self, x, eval=False):
         return self.backend.forward(x, train=self.training)
 
-    def backward(self, dcom, ddes):
-        return self.backend.backward(dcom, ddes)
+    def backward(self, dcom, ddes, want_dfeats=False):
+        return self.backend.backward(dcom, ddes, want_dfeats=want_dfeats)
 
     def state_dict(self, *a, **kw):
         return self.backend.state_dict()
@@ -471,11 +480,14 @@ def se_resnet34(**kwargs):
 class ssl_resnet34(torch.nn.Module):
     """senet.py:162-185: XLS-R features [B,T,1024] -> unsqueeze(1) -> SE-ResNet34."""
 
-    def __init__(self, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, state_dict=None):
+    def __init__(self, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, state_dict=None, finetune_ssl=False, seed=1):
         super().__init__()
         from .xlsr import SSLModel
-        self.frontend = SSLModel(device, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype)
-        self.resnet34 = se_resnet34(state_dict=state_dict, device=device)
+        self.frontend = SSLModel(device, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, finetune=finetune_ssl)
+        self.resnet34 = se_resnet34(state_dict=state_dict, device=device, seed=seed)
+        # the names OcTrainer drives (shared with AModel)
+        self.ssl_model = self.frontend
+        self.backend = self.resnet34.backend
 
     def forward(self, x):
         feats = self.frontend.model.forward(x, out_dtype=torch.float32)

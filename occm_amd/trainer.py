@@ -1,5 +1,6 @@
-"""One training step of the hot path: (RawBoost ->) XLS-R front-end -> AASIST back-end -> losses -> backward ->
-gradient all-reduce -> Adam.  Mirrors the loop body of oc_training.py:363-385."""
+"""One training step of the hot path: (RawBoost ->) XLS-R front-end -> AASIST or SE-ResNet34 back-end -> losses ->
+backward -> gradient all-reduce -> Adam.  Mirrors the loop bodies of oc_training.py:363-385 and
+test_dataloader_v2.py:107-130."""
 import torch
 
 from . import ops
@@ -7,8 +8,9 @@ from .parallel import FlatGradAllReducer
 
 
 class OcTrainer:
-    """model: occm_amd.models.sslassist.AModel.  Loss weights default to the committed 0.0 / 1.0 (oc_training.py:380-381);
-    the SE-ResNet script uses 0.1 / 0.9 (test_dataloader_v2.py:127)."""
+    """model: occm_amd.models.sslassist.AModel or occm_amd.models.senet.ssl_resnet34 (anything with ``.ssl_model.model`` and a
+    ``.backend`` engine offering forward/backward/zero_grad and flat P/G buffers).  Loss weights default to the committed
+    0.0 / 1.0 (oc_training.py:380-381); the SE-ResNet script uses 0.1 / 0.9 (test_dataloader_v2.py:127)."""
 
     def __init__(self, model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=False, group_size=None, dropout_masks=None, rawboost_algo=0,
                  rawboost_args=None, seed=0):
@@ -19,7 +21,7 @@ class OcTrainer:
         self.fe = model.ssl_model.model
         self.train_frontend = train_frontend
         if train_frontend and not hasattr(self.fe, "forward_train"):
-            raise ValueError("train_frontend=True needs AModel(..., finetune_ssl=True)")
+            raise ValueError("train_frontend=True needs a model built with finetune_ssl=True")
         self.w_c, self.w_d = w_compact, w_descr
         self.group_size = group_size
         params, self._grads = [self.be.P], [self.be.G]

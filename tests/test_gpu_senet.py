@@ -114,7 +114,8 @@ def test_senet_gradients_match_oracle_autograd(shape, seed):
     dcom = torch.randn(B, 128, generator=torch.Generator().manual_seed(20))
     ddes = torch.randn(B, 2, generator=torch.Generator().manual_seed(21))
     q = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in p.items()}
-    com, des = senet_ref.senet34_forward(x, q, train=True)
+    xr = x.clone().requires_grad_(True)
+    com, des = senet_ref.senet34_forward(xr, q, train=True)
     ((com * dcom).sum() + (des * ddes).sum()).backward()
 
     net = se_resnet34(state_dict=p)
@@ -123,7 +124,8 @@ def test_senet_gradients_match_oracle_autograd(shape, seed):
     torch.testing.assert_close(com_g.cpu(), com.detach(), rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(des_g.cpu(), des.detach(), rtol=1e-3, atol=1e-3)
     net.backend.zero_grad()
-    net.backward(dcom.cuda(), ddes.cuda())
+    dx = net.backward(dcom.cuda(), ddes.cuda(), want_dfeats=True)
+    torch.testing.assert_close(dx.cpu(), xr.grad[:, 0], rtol=2e-3, atol=2e-3 * float(xr.grad.abs().max()))
     grads = net.backend.grad_dict()
     bad = []
     for k, v in q.items():
@@ -186,3 +188,28 @@ def test_senet_gradients_full_size_features():
     assert not bad, bad
     a, b = torch.cat(a), torch.cat(b)
     assert float(torch.dot(a, b) / (a.norm() * b.norm())) >= 0.999
+
+
+@pytest.mark.parametrize("finetune", [False, "full"])
+def test_ssl_resnet34_trainer_learns(finetune):
+    """test_dataloader_v2.py:107-130 loop body (XLS-R -> unsqueeze -> SE-ResNet34 -> 0.1 c + 0.9 d -> Adam) on a fixed group of 12."""
+    from occm_amd.models import xlsr
+    from occm_amd.models.senet import ssl_resnet34
+    from occm_amd.trainer import OcTrainer
+    cfg = xlsr.XlsrConfig(dim=256, ffn=512, heads=4, layers=2)
+    model = ssl_resnet34("cuda", ssl_cfg=cfg, finetune_ssl=finetune)
+    model.train()
+    tr = OcTrainer(model, lr=1e-3 if not finetune else 2e-4, w_compact=0.1, w_descr=0.9, train_frontend=bool(finetune))
+    wav = (0.1 * _x((12, 16000), 1)).cuda()
+    labels = (torch.arange(12) >= 6).long().cuda()
+    before = model.backend.P.clone()
+    losses = []
+    for _ in range(8):
+        lc, ld = tr.step(wav, labels)
+        losses.append(0.1 * float(lc) + 0.9 * float(ld))
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    assert not torch.equal(before, model.backend.P)
+    model.eval()
+    com, des = model(wav)
+    assert com.shape == (12, 128) and des.shape == (12, 2)
