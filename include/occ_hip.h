@@ -124,6 +124,13 @@ typedef struct occ_gemm_desc {
 /* C = act(alpha * A.W^T + bias) + R.  Replaces every nn.Linear / Conv1d of the path
  * (fairseq wav2vec2 layers reached from sslassist.py:48; AModel.LL sslassist.py:509).             */
 int occ_gemm(const occ_gemm_desc* d, void* stream);
+/* Tuning hook: selects the bf16 kernel family occ_gemm dispatches to (1 = default heuristic; other values force one
+ * experimental kernel, see csrc/gemm.hip); v < 0 only queries.  Returns the previous value.  Initialised from the
+ * OCC_GEMM_VARIANT environment variable.  Results are identical across variants up to f32 summation order.          */
+int occ_gemm_variant(int v);
+/* Ablation bits for timing experiments (1: no operand loads in the K loop, 2: no MFMA, 4: no fragment reads); results are
+ * WRONG while any bit is set.  bits < 0 only queries; returns the previous value.  Never set by the product code.        */
+int occ_gemm_debug(int bits);
 
 
 /* Weight-gradient GEMM (f32): C[n1,n2] += alpha * sum_m A[m,n1] * B[m,n2]; A rows [N1] and B rows [N2] go through

@@ -179,3 +179,21 @@ def test_sslmodel_dropin_surface():
     y = m.extract_feat(x)
     y3 = m.extract_feat(x.unsqueeze(-1))          # sslassist.py:42-43: [B,L,1] accepted
     assert m.out_dim == 256 and y.shape == (2, 12, 256) and torch.equal(y, y3)
+
+
+@pytest.mark.parametrize("variant", [3, 5, 6, 8, 9, 11, 12, 13])
+def test_bf16_gemm_kernel_family_agrees(variant):
+    """occ_gemm_variant selects other kernels of the bf16 family (256-wide tile, multi-stage LDS pipelines, persistent forms).
+    They are tuning alternatives of the default and must give the same results on ragged tiles, conv windows and the grouped,
+    K-segmented positional conv."""
+    from occm_amd._lib import lib
+    prev = lib().occ_gemm_variant(variant)
+    try:
+        for M, N, K in [(128, 128, 128), (6368, 1024, 512), (333, 132, 1536), (257, 3072, 64), (700, 260, 192)]:
+            test_linear_bias_act_residual(M, N, K, "bf16")
+        test_linear_bf16_output_and_alpha()
+        test_conv1d_as_window_gemm(torch.bfloat16, 3, 2, 12799)
+        test_grouped_pos_conv_gelu_residual(torch.bfloat16)
+    finally:
+        lib().occ_gemm_variant(prev)
+    assert lib().occ_gemm_variant(-1) == prev
