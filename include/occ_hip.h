@@ -144,6 +144,7 @@ typedef struct occ_gemm_tn_desc {
     float alpha;
     void* colsum;                      /* optional f32 [N1]: += alpha * column sums of A (the bias gradient), or NULL */
     int a_dtype, b_dtype;              /* OCC_F32 (0, default) or OCC_BF16: operand storage; products and sums are f32 either way */
+    int compute;                       /* OCC_F32 (0, default): exact-f32 MFMA; OCC_BF16: operands rounded to bf16, bf16 MFMA, f32 accumulate */
 } occ_gemm_tn_desc;
 int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream);
 /* out[n] += alpha * sum_m A[m,n] (bias gradients).                                                   */

@@ -30,7 +30,7 @@ def full(rows, C):
     return RowMap(int(rows), 0, int(C), 0, 0)
 
 
-def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsum_out=None, a_bf16=False, b_bf16=False):
+def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsum_out=None, a_bf16=False, b_bf16=False, bf16_mfma=False):
     d = GemmTnDesc()
     d.M, d.N1, d.N2 = int(M), int(N1), int(N2)
     d.A, d.a_map = _ai(A), a_map
@@ -42,6 +42,7 @@ def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsu
     d.C, d.ldc, d.alpha = _ai(C), int(ldc), float(alpha)
     d.colsum = _ai(colsum_out)
     d.a_dtype, d.b_dtype = int(bool(a_bf16)), int(bool(b_bf16))
+    d.compute = 1 if bf16_mfma else 0          # OCC_BF16 / OCC_F32
     check(lib().occ_gemm_tn(ctypes.byref(d), stream_ptr()), "occ_gemm_tn")
 
 

@@ -116,6 +116,120 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16-MFMA form (occ_gemm_tn_desc.compute = OCC_BF16): operands are rounded to bf16 while they are staged, products are
+// accumulated in f32 by v_mfma_f32_16x16x32_bf16 -- 16x the MFMA rate of the exact-f32 form, which turns the kernel from
+// MFMA-bound into load-bound.  The reduction index m is the LDS row, so a fragment (8 consecutive k per lane) is a COLUMN
+// piece of the staged slab: read with ds_read_b64_tr_b16 (gfx950 transposing read; 4 rows x 16 columns per 16-lane group).
+// k-slot (g, h, q) of a 32-row block maps to LDS row 16h + 4g + q on BOTH operands (any bijection works for a dot product);
+// with a 160-byte row stride the 8 consecutive rows a 32-lane half touches fall on 8 disjoint bank octets.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+constexpr int SLABB = 64, ROWB = 160;            // rows per slab, bytes per LDS row (64 bf16 + pad)
+
+template <bool ABF, bool BBF>
+__global__ __launch_bounds__(THREADS) void gemm_tn_bf16_kernel(const TnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[SLABB * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[SLABB * ROWB];
+    const long long n1_0 = (long long)blockIdx.x * TT, n2_0 = (long long)blockIdx.y * TT;
+    const long long m_begin = (long long)blockIdx.z * a.rows_per_split;
+    const long long m_end = m_begin + a.rows_per_split < a.M ? m_begin + a.rows_per_split : a.M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1, fr = lane & 15, g = lane >> 4;
+    const int c4 = tid & 15, srow = tid >> 4;
+    const long long n1c = n1_0 + c4 * 4, n2c = n2_0 + c4 * 4;
+    const bool a_ok = n1c < a.N1, b_ok = n2c < a.N2;
+    long long bseg_off = 0;
+    if (b_ok) {
+        if (a.nseg > 1) { const long long sg = n2c / a.seg_len; bseg_off = sg * a.seg_stride + (n2c - sg * a.seg_len); }
+        else bseg_off = n2c;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 va[4], vb[4];
+    auto fetch = [&](long long m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long m = m0 + srow + 16 * i;
+            va[i] = make_float4(0.f, 0.f, 0.f, 0.f); vb[i] = va[i];
+            if (m < m_end) {
+                if (a_ok) va[i] = ABF ? ld4_bf16((const unsigned short*)a.A + row_off(a.amap, m) + n1c)
+                                      : *reinterpret_cast<const float4*>((const float*)a.A + row_off(a.amap, m) + n1c);
+                if (b_ok) vb[i] = BBF ? ld4_bf16((const unsigned short*)a.B + row_off(a.bmap, m) + bseg_off)
+                                      : *reinterpret_cast<const float4*>((const float*)a.B + row_off(a.bmap, m) + bseg_off);
+            }
+        }
+    };
+    auto pack4 = [](const float4 v) {
+        return make_uint2((unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16),
+                          (unsigned)f32_to_bf16_bits(v.z) | ((unsigned)f32_to_bf16_bits(v.w) << 16));
+    };
+    // per-lane byte offsets of the transposing reads: row 16h + 4g + q, columns 4p .. 4p+3 of the fragment's 16 columns
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int roff = (4 * g + q) * ROWB + p * 8;
+    fetch(m_begin);
+    for (long long m0 = m_begin; m0 < m_end; m0 += SLABB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { csum.x += va[i].x; csum.y += va[i].y; csum.z += va[i].z; csum.w += va[i].w; }
+        __syncthreads();                                   // previous slab fully consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint2*>(&As[(srow + 16 * i) * ROWB + c4 * 8]) = pack4(va[i]);
+            *reinterpret_cast<uint2*>(&Bs[(srow + 16 * i) * ROWB + c4 * 8]) = pack4(vb[i]);
+        }
+        __syncthreads();
+        if (m0 + SLABB < m_end) fetch(m0 + SLABB);         // next slab's loads fly under the MFMAs below
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8_t af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int base = kb * 32 * ROWB + roff;
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + base + (wi * 32 + i * 16) * 2));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + base + 16 * ROWB + (wi * 32 + i * 16) * 2));
+                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + base + (wj * 32 + i * 16) * 2));
+                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + base + 16 * ROWB + (wj * 32 + i * 16) * 2));
+                af[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                bf[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (a.colsum && blockIdx.y == 0) {                     // bias gradient (sums of the un-rounded values)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(As);         // 16 x 64 f32 = 4 KiB of the 10 KiB buffer
+        *reinterpret_cast<float4*>(&red[srow * 64 + c4 * 4]) = csum;
+        __syncthreads();
+        if (tid < TT && n1_0 + tid < a.N1) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[r * 64 + tid];
+            atomicAdd(a.colsum + n1_0 + tid, s * a.alpha);
+        }
+    }
+    // D[row = n1][col = n2]: lane holds col fr, rows 4g + r
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n2 = n2_0 + wj * 32 + j * 16 + fr;
+            if (n2 >= a.N2) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long n1 = n1_0 + wi * 32 + i * 16 + g * 4 + r;
+                if (n1 < a.N1) atomicAdd(a.C + n1 * a.ldc + n2, acc[i][j][r] * a.alpha);
+            }
+        }
+}
+
 // out[n] += alpha * sum_m A[m, n]
 template <typename T>
 __global__ __launch_bounds__(THREADS) void colsum_kernel(const T* __restrict__ A, RowMapI amap, long long M, long long N,
@@ -160,13 +274,22 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
     if (split > 65535) split = 65535;
-    a.rows_per_split = occ_cdiv(occ_cdiv(d->M, split), SLAB) * SLAB;
+    a.rows_per_split = occ_cdiv(occ_cdiv(d->M, split), SLABB) * SLABB;          // multiple of both kernels' slab heights
     split = occ_cdiv(d->M, a.rows_per_split);
     OCC_CHECK_ARG(t1 < 65536 && t2 < 65536, "occ_gemm_tn: output too large");
     const dim3 grid((unsigned)t1, (unsigned)t2, (unsigned)split);
     const bool abf = d->a_dtype == OCC_BF16, bbf = d->b_dtype == OCC_BF16;
     OCC_CHECK_ARG((abf || d->a_dtype == OCC_F32) && (bbf || d->b_dtype == OCC_F32), "occ_gemm_tn: operand dtypes must be f32 or bf16");
     hipStream_t s = (hipStream_t)stream;
+    OCC_CHECK_ARG(d->compute == OCC_F32 || d->compute == OCC_BF16, "occ_gemm_tn: compute must be OCC_F32 or OCC_BF16");
+    if (d->compute == OCC_BF16) {
+        if (abf && bbf) hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, dim3(THREADS), 0, s, a);
+        else if (abf) hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, dim3(THREADS), 0, s, a);
+        else if (bbf) hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, true>), grid, dim3(THREADS), 0, s, a);
+        else hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, dim3(THREADS), 0, s, a);
+        OCC_LAUNCH_CHECK("occ_gemm_tn");
+        return OCC_OK;
+    }
     if (abf && bbf) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, dim3(THREADS), 0, s, a);
     else if (abf) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, dim3(THREADS), 0, s, a);
     else if (bbf) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, dim3(THREADS), 0, s, a);

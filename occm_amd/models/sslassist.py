@@ -13,6 +13,8 @@ running statistics still move (:409-415); the returned ``emb`` is the dropped-ou
 """
 import math
 
+import functools
+
 import torch
 
 from .. import backend_ops as K
@@ -99,6 +101,8 @@ class AasistBackend:
         if compute not in ("f32", "bf16"):
             raise OccError("compute must be 'f32' or 'bf16'")
         self.compute = compute
+        # weight gradients: exact-f32 MFMA on the parity path, bf16 MFMA (f32 accumulate) in bf16 compute mode
+        self._tn = functools.partial(K.gemm_tn, bf16_mfma=(compute == "bf16"))
         self.device = torch.device(device)
         self.table = backend_param_table()
         # ---- flat parameter / gradient storage (one Adam tensor, one all-reduce bucket) ----
@@ -244,7 +248,7 @@ class AasistBackend:
 
     def _lin_bwd(self, dy, dy_map, x, x_map, M, Kd, name, N, dx=None, dx_map=None, dx_R=None, dx_rmap=None, need_dx=True):
         """dW += dy^T x, db += colsum(dy), dx = dy W (+R).  dy rows [N] via dy_map, x rows [Kd] via x_map."""
-        K.gemm_tn(M, N, Kd, dy, dy_map, x, x_map, self.g[name + ".weight"], Kd, colsum_out=self.g[name + ".bias"])
+        self._tn(M, N, Kd, dy, dy_map, x, x_map, self.g[name + ".weight"], Kd, colsum_out=self.g[name + ".bias"])
         if not need_dx:
             return None
         wt = self._e(Kd, N)
@@ -589,7 +593,7 @@ class AasistBackend:
             R1 = B * 43 * W
             d_in = D.data_ptr() + (Wp + 1) * co * es                   # grad wrt block output, interior of D
             # conv2: wgrad, bias grad, dgrad
-            K.gemm_tn(R, co, 6 * co, d_in, mp["x_in42"](co), Y, mp["y_win42"](co), g[pre + ".conv2.weight"], 6 * co, b_seg=(2, 3 * co, Wp * co),
+            self._tn(R, co, 6 * co, d_in, mp["x_in42"](co), Y, mp["y_win42"](co), g[pre + ".conv2.weight"], 6 * co, b_seg=(2, 3 * co, Wp * co),
                       colsum_out=g[pre + ".conv2.bias"])
             wd = self._e(co, 2, 3, co)
             K.copy_strided(p[pre + ".conv2.weight"], wd, 3 * co + 2 * co, (co, 2, 3, co), (1, -3 * co, -co, 6 * co))
@@ -600,11 +604,11 @@ class AasistBackend:
                          ACT_SELU, D1.data_ptr() + co * es, mp["y_in43"](co), g[pre + ".bn2.weight"], g[pre + ".bn2.bias"], self.bn_ws,
                          self.bn_sums, R1, co)
             d1_in = D1.data_ptr() + co * es
-            K.gemm_tn(R1, co, 6 * ci, d1_in, mp["y_in43"](co), X, mp["x_win43"](ci), g[pre + ".conv1.weight"], 6 * ci, b_seg=(2, 3 * ci, Wp * ci),
+            self._tn(R1, co, 6 * ci, d1_in, mp["y_in43"](co), X, mp["x_win43"](ci), g[pre + ".conv1.weight"], 6 * ci, b_seg=(2, 3 * ci, Wp * ci),
                       colsum_out=g[pre + ".conv1.bias"])
             # identity path
             if ci0 != co:
-                K.gemm_tn(R, co, 3 * ci, d_in, mp["x_in42"](co), X.data_ptr() + Wp * ci * es, mp["x_in42"](ci), g[pre + ".conv_downsample.weight"], 3 * ci,
+                self._tn(R, co, 3 * ci, d_in, mp["x_in42"](co), X.data_ptr() + Wp * ci * es, mp["x_in42"](ci), g[pre + ".conv_downsample.weight"], 3 * ci,
                           colsum_out=g[pre + ".conv_downsample.bias"])
                 wdd = self._e(ci, 1, 3, co)
                 K.copy_strided(p[pre + ".conv_downsample.weight"], wdd, 2 * ci, (ci, 1, 3, co), (1, 0, -ci, 3 * ci))

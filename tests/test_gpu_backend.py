@@ -302,3 +302,30 @@ def test_backend_bf16_compute_mode_tracks_the_f32_mode():
           % (dS, dT, dloss, worst, wname, flat))
     assert dS < 0.06 and dT < 0.06 and dloss < 0.05
     assert worst > 0.9 and flat > 0.95
+
+
+@pytest.mark.parametrize("M,N1,N2,seg", [(1000, 64, 64, None), (88704, 64, 384, "conv"), (517, 128, 1024, None), (33, 4, 24, None), (4099, 32, 192, None)])
+def test_gemm_tn_bf16_mfma(M, N1, N2, seg):
+    """compute = OCC_BF16 form of the weight-gradient GEMM (transposing LDS reads): equals the f64 product of the bf16-rounded
+    operands to f32 summation accuracy; the fused bias gradient stays a sum of the un-rounded values."""
+    from occm_amd import backend_ops as K
+    a = _r(M, N1, seed=1)
+    if seg == "conv":            # B rows are 2x3 windows over a [*, 68, 64] channels-last image: 2 K-segments of 192
+        Wp, ci = 68, 64
+        img = _r(M // 66 + 3, Wp, ci, seed=2)
+        imgd = img.cuda()
+        rows = torch.arange(M)
+        h, w = rows // 66, rows % 66
+        win = torch.stack([img[h + dh, w + dw] for dh in range(2) for dw in range(3)], 1).reshape(M, 6 * ci)
+        b_ref, Bm, b_seg = win, imgd, (2, 3 * ci, Wp * ci)
+        b_map = K.rowmap(66 * (M // 66 + 1), 0, ci, 66, Wp * ci)     # one "batch" of lines: row r -> line r // 66, column r % 66
+    else:
+        b = _r(M, N2, seed=2)
+        b_ref, Bm, b_map, b_seg = b, b.cuda(), K.full(M, N2), None
+    C, s = torch.zeros(N1, N2).cuda(), torch.zeros(N1).cuda()
+    K.gemm_tn(M, N1, N2, a.cuda(), K.full(M, N1), Bm, b_map, C, N2, b_seg=b_seg, colsum_out=s, bf16_mfma=True)
+    ref = a.bfloat16().double().T @ b_ref.bfloat16().double()
+    torch.testing.assert_close(C.cpu().double(), ref, rtol=1e-4, atol=2e-6 * float(ref.abs().max()) + 1e-4)
+    torch.testing.assert_close(s.cpu().double(), a.double().sum(0), rtol=1e-4, atol=1e-3)
+    exact = a.double().T @ b_ref.double()                      # and it is close to the un-rounded product (bf16 products, f32 sums)
+    assert float((C.cpu().double() - exact).abs().max()) <= 2e-2 * float(exact.abs().max()) + 1e-3
