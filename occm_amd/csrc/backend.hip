@@ -254,6 +254,107 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, RowMapI dymap,
     }
 }
 
+// ---- float4 forms of the four BatchNorm kernels for C % 4 == 0 (every layer but the 1-channel stem): 16-byte accesses, a
+// thread owns one 4-column group, 32-bit index math; same partial-sum workspace layout as the scalar kernels.
+__global__ __launch_bounds__(BT) void bn_partial_vec_kernel(const float* __restrict__ x, RowMapI map, long long rows, int C, long long rows_per_chunk,
+                                                            double* __restrict__ ws) {
+    __shared__ double red[BT][8];
+    const int cq = C >> 2, g = threadIdx.x % cq, rl = threadIdx.x / cq, rstep = BT / cq;
+    const long long begin = (long long)blockIdx.x * rows_per_chunk;
+    const long long end = begin + rows_per_chunk < rows ? begin + rows_per_chunk : rows;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (long long r = begin + rl; r < end; r += rstep) {
+        const float4 v = *reinterpret_cast<const float4*>(x + row_off(map, r) + 4 * g);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][4 + e] = q[e]; }
+    __syncthreads();
+    if (threadIdx.x < C) {                       // thread = one column: gather its group's partials over the row lanes
+        const int gg = threadIdx.x >> 2, e = threadIdx.x & 3;
+        double ss = 0.0, qq = 0.0;
+        for (int k = 0; k < rstep; ++k) { ss += red[gg + k * cq][e]; qq += red[gg + k * cq][4 + e]; }
+        ws[((size_t)blockIdx.x * C + threadIdx.x) * 2] = ss;
+        ws[((size_t)blockIdx.x * C + threadIdx.x) * 2 + 1] = qq;
+    }
+}
+template <int ACT>
+__global__ void bn_act_fwd_vec_kernel(const float* __restrict__ x, RowMapI xmap, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, RowMapI ymap,
+                                      long long rows, int C) {
+    const unsigned cq = (unsigned)C >> 2;
+    const long long n = rows * cq;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = n < (1ll << 31) ? (long long)((unsigned)i / cq) : i / cq;
+        const int c = (int)(i - r * cq) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + row_off(xmap, r) + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+        float4 o;
+        o.x = occ_apply_act<ACT>((v.x - mu.x) * rs.x * ga.x + be.x); o.y = occ_apply_act<ACT>((v.y - mu.y) * rs.y * ga.y + be.y);
+        o.z = occ_apply_act<ACT>((v.z - mu.z) * rs.z * ga.z + be.z); o.w = occ_apply_act<ACT>((v.w - mu.w) * rs.w * ga.w + be.w);
+        *reinterpret_cast<float4*>(y + row_off(ymap, r) + c) = o;
+    }
+}
+template <int ACT>
+__global__ __launch_bounds__(BT) void bn_bwd_partial_vec_kernel(const float* __restrict__ dy, RowMapI dymap, const float* __restrict__ x, RowMapI xmap,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, long long rows, int C,
+                                                                long long rows_per_chunk, double* __restrict__ ws) {
+    __shared__ double red[BT][8];
+    const int cq = C >> 2, g = threadIdx.x % cq, rl = threadIdx.x / cq, rstep = BT / cq;
+    const long long begin = (long long)blockIdx.x * rows_per_chunk;
+    const long long end = begin + rows_per_chunk < rows ? begin + rows_per_chunk : rows;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * g), rs = *reinterpret_cast<const float4*>(rstd + 4 * g);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * g), be = *reinterpret_cast<const float4*>(beta + 4 * g);
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (long long r = begin + rl; r < end; r += rstep) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + row_off(xmap, r) + 4 * g);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + row_off(dymap, r) + 4 * g);
+        const float xh[4] = {(xv.x - mu.x) * rs.x, (xv.y - mu.y) * rs.y, (xv.z - mu.z) * rs.z, (xv.w - mu.w) * rs.w};
+        const float dz[4] = {dv.x * act_grad<ACT>(xh[0] * ga.x + be.x), dv.y * act_grad<ACT>(xh[1] * ga.y + be.y),
+                             dv.z * act_grad<ACT>(xh[2] * ga.z + be.z), dv.w * act_grad<ACT>(xh[3] * ga.w + be.w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += (double)dz[e]; q[e] += (double)dz[e] * (double)xh[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][4 + e] = q[e]; }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const int gg = threadIdx.x >> 2, e = threadIdx.x & 3;
+        double ss = 0.0, qq = 0.0;
+        for (int k = 0; k < rstep; ++k) { ss += red[gg + k * cq][e]; qq += red[gg + k * cq][4 + e]; }
+        ws[((size_t)blockIdx.x * C + threadIdx.x) * 2] = ss;
+        ws[((size_t)blockIdx.x * C + threadIdx.x) * 2 + 1] = qq;
+    }
+}
+template <int ACT>
+__global__ void bn_bwd_apply_vec_kernel(const float* __restrict__ dy, RowMapI dymap, const float* __restrict__ x, RowMapI xmap,
+                                        const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, const float* __restrict__ sums, float* __restrict__ dx, RowMapI dxmap,
+                                        long long rows, int C) {
+    const unsigned cq = (unsigned)C >> 2;
+    const long long n = rows * cq;
+    const float invn = 1.0f / (float)rows;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = n < (1ll << 31) ? (long long)((unsigned)i / cq) : i / cq;
+        const int c = (int)(i - r * cq) * 4;
+        const float4 xv = *reinterpret_cast<const float4*>(x + row_off(xmap, r) + c);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + row_off(dymap, r) + c);
+        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, da[4] = {dv.x, dv.y, dv.z, dv.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float rs = rstd[c + e], ga = gamma[c + e];
+            const float xh = (xa[e] - mean[c + e]) * rs;
+            const float dz = da[e] * act_grad<ACT>(xh * ga + beta[c + e]);
+            o[e] = ga * rs * (dz - sums[2 * (c + e)] * invn - xh * sums[2 * (c + e) + 1] * invn);
+        }
+        *reinterpret_cast<float4*>(dx + row_off(dxmap, r) + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ------------------------------------------------------- softmax-weighted sum along one axis --
 // element (o, r, c) of x / w lives at (o / inner_n) * outer_stride + (o % inner_n) * inner_stride + r * r_stride + c.
 // out[o, c] = sum_r x * softmax_r(w) (+ pos[(o % pos_period), c]).          sslassist.py:526-538
@@ -1024,9 +1125,15 @@ int occ_stem_pool_bwd(const float* dout, const uint8_t* idx, float* dy, int64_t 
     return OCC_OK;
 }
 
-static int bn_chunks(int64_t rows, long long* rpc) {
-    long long nchunk = occ_cdiv(rows, 256);
-    if (nchunk > 512) nchunk = 512;
+static bool bn_vec(const occ_rowmap& m, int64_t C, const void* p) {
+    return C % 4 == 0 && m.row_stride % 4 == 0 && m.batch_stride % 4 == 0 && m.line_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+// chunks of the row range for the partial sums; the f64 workspace [nchunk][C][2] holds at most 512*256*2 entries
+static int bn_chunks(int64_t rows, int64_t C, long long* rpc) {
+    long long nchunk = occ_cdiv(rows, 64);
+    const long long cap = C % 4 == 0 ? (512 * 256) / C : 512;
+    if (nchunk > cap) nchunk = cap;
+    if (nchunk > 2048) nchunk = 2048;
     *rpc = occ_cdiv(rows, nchunk);
     return (int)occ_cdiv(rows, *rpc);
 }
@@ -1037,8 +1144,9 @@ int occ_bn_stats(const float* x, const occ_rowmap* x_map, int64_t rows, int64_t 
     hipStream_t s = (hipStream_t)stream;
     int nchunk = 0;
     if (train) {
-        long long rpc; nchunk = bn_chunks(rows, &rpc);
-        hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk), dim3(BT), 0, s, x, to_rowmap(*x_map), (long long)rows, (int)C, rpc, ws);
+        long long rpc; nchunk = bn_chunks(rows, C, &rpc);
+        if (bn_vec(*x_map, C, x)) hipLaunchKernelGGL(bn_partial_vec_kernel, dim3(nchunk), dim3(BT), 0, s, x, to_rowmap(*x_map), (long long)rows, (int)C, rpc, ws);
+        else hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk), dim3(BT), 0, s, x, to_rowmap(*x_map), (long long)rows, (int)C, rpc, ws);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)occ_cdiv(C, BT / 64)), dim3(BT), 0, s, (const double*)ws, nchunk, (int)C, (long long)rows, mean, rstd,
                        running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, train);
@@ -1051,6 +1159,15 @@ int occ_bn_act_fwd(const float* x, const occ_rowmap* x_map, const float* mean, c
     const dim3 grid(grid_for(rows * C)), block(BT);
     hipStream_t s = (hipStream_t)stream;
     const RowMapI xm = to_rowmap(*x_map), ym = to_rowmap(*y_map);
+    if (bn_vec(*x_map, C, x) && bn_vec(*y_map, C, y) && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)rstd & 15) == 0 && ((uintptr_t)gamma & 15) == 0 &&
+        ((uintptr_t)beta & 15) == 0 && (act == OCC_ACT_SELU || act == OCC_ACT_RELU || act == OCC_ACT_NONE)) {
+        const dim3 gv(grid_for(rows * C / 4));
+        if (act == OCC_ACT_SELU) hipLaunchKernelGGL(bn_act_fwd_vec_kernel<OCC_ACT_SELU>, gv, block, 0, s, x, xm, mean, rstd, gamma, beta, y, ym, (long long)rows, (int)C);
+        else if (act == OCC_ACT_RELU) hipLaunchKernelGGL(bn_act_fwd_vec_kernel<OCC_ACT_RELU>, gv, block, 0, s, x, xm, mean, rstd, gamma, beta, y, ym, (long long)rows, (int)C);
+        else hipLaunchKernelGGL(bn_act_fwd_vec_kernel<OCC_ACT_NONE>, gv, block, 0, s, x, xm, mean, rstd, gamma, beta, y, ym, (long long)rows, (int)C);
+        OCC_LAUNCH_CHECK("occ_bn_act_fwd");
+        return OCC_OK;
+    }
     if (act == OCC_ACT_SELU) hipLaunchKernelGGL(bn_act_fwd_kernel<OCC_ACT_SELU>, grid, block, 0, s, x, xm, mean, rstd, gamma, beta, y, ym, (long long)rows, (int)C);
     else if (act == OCC_ACT_RELU) hipLaunchKernelGGL(bn_act_fwd_kernel<OCC_ACT_RELU>, grid, block, 0, s, x, xm, mean, rstd, gamma, beta, y, ym, (long long)rows, (int)C);
     else if (act == OCC_ACT_NONE) hipLaunchKernelGGL(bn_act_fwd_kernel<OCC_ACT_NONE>, grid, block, 0, s, x, xm, mean, rstd, gamma, beta, y, ym, (long long)rows, (int)C);
@@ -1064,9 +1181,23 @@ int occ_bn_act_bwd(const float* dy, const occ_rowmap* dy_map, const float* x, co
     OCC_CHECK_ARG(dy && dy_map && x && x_map && mean && rstd && gamma && beta && dx && dx_map && ws && sums, "occ_bn_act_bwd: null pointer");
     OCC_CHECK_ARG(rows >= 1 && C >= 1 && C <= 256 && 256 % C == 0, "occ_bn_act_bwd: C must divide 256");
     hipStream_t s = (hipStream_t)stream;
-    long long rpc; const int nchunk = bn_chunks(rows, &rpc);
+    long long rpc; const int nchunk = bn_chunks(rows, C, &rpc);
     const RowMapI dym = to_rowmap(*dy_map), xm = to_rowmap(*x_map), dxm = to_rowmap(*dx_map);
     const dim3 grid(grid_for(rows * C)), block(BT);
+    if (bn_vec(*dy_map, C, dy) && bn_vec(*x_map, C, x) && bn_vec(*dx_map, C, dx) && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)rstd & 15) == 0 &&
+        ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0 && (act == OCC_ACT_SELU || act == OCC_ACT_RELU || act == OCC_ACT_NONE)) {
+        const dim3 gv(grid_for(rows * C / 4));
+#define OCC_BN_BWD_V(A)                                                                                                                    \
+    hipLaunchKernelGGL(bn_bwd_partial_vec_kernel<A>, dim3(nchunk), block, 0, s, dy, dym, x, xm, mean, rstd, gamma, beta, (long long)rows, (int)C, rpc, ws); \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(C, BT / 64)), dim3(BT), 0, s, (const double*)ws, nchunk, (int)C, sums, dgamma, dbeta); \
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<A>, gv, block, 0, s, dy, dym, x, xm, mean, rstd, gamma, beta, (const float*)sums, dx, dxm, (long long)rows, (int)C)
+        if (act == OCC_ACT_SELU) { OCC_BN_BWD_V(OCC_ACT_SELU); }
+        else if (act == OCC_ACT_RELU) { OCC_BN_BWD_V(OCC_ACT_RELU); }
+        else { OCC_BN_BWD_V(OCC_ACT_NONE); }
+#undef OCC_BN_BWD_V
+        OCC_LAUNCH_CHECK("occ_bn_act_bwd");
+        return OCC_OK;
+    }
 #define OCC_BN_BWD(A)                                                                                                                      \
     hipLaunchKernelGGL(bn_bwd_partial_kernel<A>, dim3(nchunk), block, 0, s, dy, dym, x, xm, mean, rstd, gamma, beta, (long long)rows, (int)C, rpc, ws); \
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(C, BT / 64)), dim3(BT), 0, s, (const double*)ws, nchunk, (int)C, sums, dgamma, dbeta); \
