@@ -120,14 +120,18 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float4 lo, const float4 hi) {
                       (unsigned)f32_to_bf16_bits(hi.z) | ((unsigned)f32_to_bf16_bits(hi.w) << 16));
 }
 
-template <int MODE>
-__global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
+// TNT = 128: 2x2 waves, 64x64 per wave, 64 KiB LDS, 2 workgroups per CU.  TNT = 64 (narrow outputs: the back-ends' 32/64-channel
+// convolutions): 4x1 waves, 32x64 per wave, 48 KiB LDS, 3 workgroups per CU, no MFMA work on columns that do not exist.
+template <int MODE, int TNT = 128>
+__global__ __launch_bounds__(THREADS, TNT == 128 ? 2 : 3) void gemm_kernel(const GemmArgs a) {
+    constexpr int NJ = TNT == 128 ? 4 : 2;      // 16-row blocks per wave
+    constexpr int WPASS = TNT / 32;             // staging passes over the W rows
     constexpr bool BF16 = MODE != 0;            // MFMA flavour
     constexpr int ES = MODE == 1 ? 2 : 4;       // element size of X in memory (MODE 3: X f32, W bf16)
     constexpr int WES = (MODE == 1 || MODE == 3) ? 2 : 4;
     constexpr int CE = BF16 ? 8 : 4;            // K elements per 16-B LDS chunk
     constexpr int SLAB_K = BF16 ? 64 : 32;      // K elements per slab
-    __shared__ uint4 lds[2][2][TM * CHUNKS];    // [buffer][X|W][row*8 + swizzled chunk]
+    __shared__ uint4 lds[2][(TM + TNT) * CHUNKS];   // [buffer][X rows, then W rows][row*8 + swizzled chunk]
 
     // ---- XCD-aware tile id: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
     // range of tiles so neighbouring tiles re-use the same X / W panels out of that L2.
@@ -136,10 +140,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
     const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
     const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
     const int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
-    const long long m0 = (long long)tile_m * TM, n0 = (long long)tile_n * TN;
+    const long long m0 = (long long)tile_m * TM, n0 = (long long)tile_n * TNT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = TNT == 128 ? (wave & 1) : wave, wn = TNT == 128 ? (wave >> 1) : 0;
     const long long grp = blockIdx.y;
     const char* Xg = a.X + grp * a.a_gstride * ES;
     const char* Wg = a.W + grp * a.w_gstride * WES;
@@ -147,17 +151,20 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
 
     // ---- staging assignment: this thread copies chunk `ch` of rows (tid>>3) + 32*i
     const int ch = tid & 7, srow = tid >> 3;
-    long long xoff[4], woff[4];
+    long long xoff[4], woff[WPASS];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         long long m = m0 + srow + 32 * i; if (m > a.M - 1) m = a.M - 1;
-        long long n = n0 + srow + 32 * i; if (n > a.N - 1) n = a.N - 1;
         xoff[i] = row_off(a.xmap, m) * ES;
+    }
+#pragma unroll
+    for (int i = 0; i < WPASS; ++i) {
+        long long n = n0 + srow + 32 * i; if (n > a.N - 1) n = a.N - 1;
         woff[i] = n * a.ldw * WES;
     }
     const int nslab = (int)((a.K + SLAB_K - 1) / SLAB_K);
 
-    uint4 px[4], pw[4];
+    uint4 px[4], pw[WPASS];
     auto issue_loads = [&](int slab) {
         const long long k0 = (long long)slab * SLAB_K + ch * CE;
         long long kx = k0;
@@ -169,16 +176,18 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
                 if (ok) {
                     const float4* xp = reinterpret_cast<const float4*>(Xg + xoff[i] + kx * ES);
                     px[i] = pack_bf16x8(xp[0], xp[1]);
-                    if constexpr (MODE == 2) {
-                        const float4* wp = reinterpret_cast<const float4*>(Wg + woff[i] + k0 * WES);
-                        pw[i] = pack_bf16x8(wp[0], wp[1]);
-                    } else {
-                        pw[i] = *reinterpret_cast<const uint4*>(Wg + woff[i] + k0 * WES);
+                    if (i < WPASS) {
+                        if constexpr (MODE == 2) {
+                            const float4* wp = reinterpret_cast<const float4*>(Wg + woff[i % WPASS] + k0 * WES);
+                            pw[i % WPASS] = pack_bf16x8(wp[0], wp[1]);
+                        } else {
+                            pw[i % WPASS] = *reinterpret_cast<const uint4*>(Wg + woff[i % WPASS] + k0 * WES);
+                        }
                     }
-                } else { px[i] = make_uint4(0, 0, 0, 0); pw[i] = px[i]; }
+                } else { px[i] = make_uint4(0, 0, 0, 0); if (i < WPASS) pw[i % WPASS] = px[i]; }
             } else {
                 px[i] = ok ? *reinterpret_cast<const uint4*>(Xg + xoff[i] + kx * ES) : make_uint4(0, 0, 0, 0);
-                pw[i] = ok ? *reinterpret_cast<const uint4*>(Wg + woff[i] + k0 * ES) : make_uint4(0, 0, 0, 0);
+                if (i < WPASS) pw[i % WPASS] = ok ? *reinterpret_cast<const uint4*>(Wg + woff[i % WPASS] + k0 * ES) : make_uint4(0, 0, 0, 0);
             }
         }
     };
@@ -187,16 +196,16 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
         for (int i = 0; i < 4; ++i) {
             const int row = srow + 32 * i;
             const int idx = row * CHUNKS + (ch ^ (row & 7));
-            lds[buf][0][idx] = px[i];
-            lds[buf][1][idx] = pw[i];
+            lds[buf][idx] = px[i];
+            if (i < WPASS) lds[buf][TM * CHUNKS + idx] = pw[i % WPASS];
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     issue_loads(0);
     write_lds(0);
@@ -208,20 +217,23 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
         if (slab + 1 < nslab) issue_loads(slab + 1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            uint4 wf[4], xf[4];
+            uint4 wf[4], xf[NJ];
             const int chk = kb * 4 + fq;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rw = wn * 64 + i * 16 + fr;
-                wf[i] = lds[cur][1][rw * CHUNKS + (chk ^ (rw & 7))];
-                const int rx = wm * 64 + i * 16 + fr;
-                xf[i] = lds[cur][0][rx * CHUNKS + (chk ^ (rx & 7))];
+                wf[i] = lds[cur][TM * CHUNKS + rw * CHUNKS + (chk ^ (rw & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int rx = wm * (NJ * 16) + j * 16 + fr;
+                xf[j] = lds[cur][rx * CHUNKS + (chk ^ (rx & 7))];
             }
             if constexpr (BF16) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
             } else {
@@ -231,7 +243,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < NJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                 reinterpret_cast<const float*>(&wf[i])[e], reinterpret_cast<const float*>(&xf[j])[e], acc[i][j], 0, 0, 0);
             }
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
-    gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+    gemm_epilogue<NJ>(a, acc, m0 + wm * (NJ * 16), n0 + wn * 64, fr, fq, cshift);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -924,6 +936,10 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 1 || variant == 4))
         hipLaunchKernelGGL(gemm_bf16_dma_kernel<128>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<1>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    else if (d->ab_dtype == OCC_F32_AS_BF16 && d->N <= 64 && g_variant != 14) {        // narrow outputs: 128x64 tile
+        a.nbn = 1;
+        hipLaunchKernelGGL((gemm_kernel<2, 64>), dim3((unsigned)a.nbm, (unsigned)ng), dim3(THREADS), 0, s, a);
+    }
     else if (d->ab_dtype == OCC_F32_AS_BF16) hipLaunchKernelGGL(gemm_kernel<2>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else if (d->ab_dtype == OCC_AF32_WBF16) hipLaunchKernelGGL(gemm_kernel<3>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else hipLaunchKernelGGL(gemm_kernel<0>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
