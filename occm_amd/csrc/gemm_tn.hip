@@ -10,6 +10,7 @@
 // owns a 32x32 quadrant = 2x2 MFMA tiles.  v_mfma_f32_16x16x4_f32 takes ONE f32 per lane for each
 // operand, so no transposed copy of either operand is ever materialised.
 #include "occ_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -23,6 +24,7 @@ struct TnArgs {
     float* C; long long ldc;
     long long rows_per_split;
     float alpha;
+    int t1, t2;               // tiles along N1 / N2 (grid is 1-D: XCD-aware order, see tn_block)
     float* colsum;            // optional: colsum[n1] += alpha * sum_m A[m, n1] (bias gradient), done by the n2-tile-0 workgroups
 };
 
@@ -31,12 +33,24 @@ __device__ __forceinline__ float4 ld4_bf16(const unsigned short* p) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
 
+// 1-D grid -> (n1 tile, n2 tile, row split).  Workgroup b runs on XCD b % 8; the blocks of one XCD get a contiguous range of
+// logical ids ordered split-major, so every tile that reads one row range sits on the same XCD and that range crosses the
+// Infinity-Cache -> L2 boundary once instead of once per XCD (measured on the 88704 x 64 x 384 conv weight gradient: the
+// un-mapped grid moved ~8x the operand bytes into the L2s and ran at 1 TB/s of unique operand bytes).
+__device__ __forceinline__ void tn_block(const TnArgs& a, int& bx, int& by, int& bz) {
+    const int total = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int l = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    bx = l % a.t1; by = (l / a.t1) % a.t2; bz = l / (a.t1 * a.t2);
+}
+
 template <bool ABF, bool BBF>      // operands f32 or bf16 in memory; the MFMA is the exact-f32 one either way
 __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
     __shared__ __attribute__((aligned(16))) float As[SLAB * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float Bs[SLAB * LDS_STRIDE];
-    const long long n1_0 = (long long)blockIdx.x * TT, n2_0 = (long long)blockIdx.y * TT;
-    const long long m_begin = (long long)blockIdx.z * a.rows_per_split;
+    int bx, by, bz; tn_block(a, bx, by, bz);
+    const long long n1_0 = (long long)bx * TT, n2_0 = (long long)by * TT;
+    const long long m_begin = (long long)bz * a.rows_per_split;
     const long long m_end = m_begin + a.rows_per_split < a.M ? m_begin + a.rows_per_split : a.M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1, fr = lane & 15, g = lane >> 4;
@@ -90,7 +104,7 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(const TnArgs a) {
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (a.colsum && blockIdx.y == 0) {                     // bias gradient: reduce the 16 row-groups through LDS
+    if (a.colsum && by == 0) {                     // bias gradient: reduce the 16 row-groups through LDS
         __syncthreads();
         *reinterpret_cast<float4*>(&As[srow * LDS_STRIDE + c4 * 4]) = csum;
         __syncthreads();
@@ -132,8 +146,9 @@ template <bool ABF, bool BBF>
 __global__ __launch_bounds__(THREADS) void gemm_tn_bf16_kernel(const TnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char As[SLABB * ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[SLABB * ROWB];
-    const long long n1_0 = (long long)blockIdx.x * TT, n2_0 = (long long)blockIdx.y * TT;
-    const long long m_begin = (long long)blockIdx.z * a.rows_per_split;
+    int bx, by, bz; tn_block(a, bx, by, bz);
+    const long long n1_0 = (long long)bx * TT, n2_0 = (long long)by * TT;
+    const long long m_begin = (long long)bz * a.rows_per_split;
     const long long m_end = m_begin + a.rows_per_split < a.M ? m_begin + a.rows_per_split : a.M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1, fr = lane & 15, g = lane >> 4;
@@ -152,17 +167,21 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_bf16_kernel(const TnArgs a) {
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 va[4], vb[4];
+    // branch-free: out-of-range rows / columns read a valid element (last row, column 0) and are zeroed by a select, so the
+    // eight loads of a slab are all in flight together instead of sitting in eight divergent regions
+    const long long acol = a_ok ? n1c : 0, bcol = b_ok ? bseg_off : 0;
     auto fetch = [&](long long m0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long long m = m0 + srow + 16 * i;
-            va[i] = make_float4(0.f, 0.f, 0.f, 0.f); vb[i] = va[i];
-            if (m < m_end) {
-                if (a_ok) va[i] = ABF ? ld4_bf16((const unsigned short*)a.A + row_off(a.amap, m) + n1c)
-                                      : *reinterpret_cast<const float4*>((const float*)a.A + row_off(a.amap, m) + n1c);
-                if (b_ok) vb[i] = BBF ? ld4_bf16((const unsigned short*)a.B + row_off(a.bmap, m) + bseg_off)
-                                      : *reinterpret_cast<const float4*>((const float*)a.B + row_off(a.bmap, m) + bseg_off);
-            }
+            const bool ok = m < m_end;
+            const long long mm = ok ? m : m_end - 1;
+            va[i] = ABF ? ld4_bf16((const unsigned short*)a.A + row_off(a.amap, mm) + acol)
+                        : *reinterpret_cast<const float4*>((const float*)a.A + row_off(a.amap, mm) + acol);
+            vb[i] = BBF ? ld4_bf16((const unsigned short*)a.B + row_off(a.bmap, mm) + bcol)
+                        : *reinterpret_cast<const float4*>((const float*)a.B + row_off(a.bmap, mm) + bcol);
+            if (!(ok && a_ok)) va[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(ok && b_ok)) vb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto pack4 = [](const float4 v) {
@@ -203,7 +222,7 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_bf16_kernel(const TnArgs a) {
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (a.colsum && blockIdx.y == 0) {                     // bias gradient (sums of the un-rounded values)
+    if (a.colsum && by == 0) {                     // bias gradient (sums of the un-rounded values)
         __syncthreads();
         float* red = reinterpret_cast<float*>(As);         // 16 x 64 f32 = 4 KiB of the 10 KiB buffer
         *reinterpret_cast<float4*>(&red[srow * 64 + c4 * 4]) = csum;
@@ -269,15 +288,17 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
     a.B = d->B; a.bmap = to_rowmap(d->b_map); a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->b_seg_stride;
     a.C = (float*)d->C; a.ldc = d->ldc; a.alpha = d->alpha; a.colsum = (float*)d->colsum;
     const long long t1 = occ_cdiv(d->N1, TT), t2 = occ_cdiv(d->N2, TT);
-    long long split = occ_cdiv(1024, t1 * t2);                       // aim at ~1024 workgroups
+    static const long long target = getenv("OCC_TN_BLOCKS") ? atoll(getenv("OCC_TN_BLOCKS")) : 1024;
+    long long split = occ_cdiv(target, t1 * t2);                     // aim at ~1024 workgroups
     const long long max_split = occ_cdiv(d->M, 4 * SLAB);            // at least 128 rows each
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
     if (split > 65535) split = 65535;
     a.rows_per_split = occ_cdiv(occ_cdiv(d->M, split), SLABB) * SLABB;          // multiple of both kernels' slab heights
     split = occ_cdiv(d->M, a.rows_per_split);
-    OCC_CHECK_ARG(t1 < 65536 && t2 < 65536, "occ_gemm_tn: output too large");
-    const dim3 grid((unsigned)t1, (unsigned)t2, (unsigned)split);
+    OCC_CHECK_ARG(t1 * t2 * split < (1ll << 30), "occ_gemm_tn: output too large");
+    a.t1 = (int)t1; a.t2 = (int)t2;
+    const dim3 grid((unsigned)(t1 * t2 * split));
     const bool abf = d->a_dtype == OCC_BF16, bbf = d->b_dtype == OCC_BF16;
     OCC_CHECK_ARG((abf || d->a_dtype == OCC_F32) && (bbf || d->b_dtype == OCC_F32), "occ_gemm_tn: operand dtypes must be f32 or bf16");
     hipStream_t s = (hipStream_t)stream;
