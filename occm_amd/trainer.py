@@ -31,18 +31,65 @@ class OcTrainer:
         self.reducers = [FlatGradAllReducer(g) for g in self._grads]
         self.reducer = self.reducers[0]
         self.last = None
+        # frozen front-end: features of the NEXT batch can be computed on a side stream while the back-end trains on this one
+        self._side = None
+        self._pref = None              # (wav tensor, features, ready event) of the prefetched batch
+        self._fbuf = [None, None]
 
-    def step(self, wav, labels):
-        """wav f32 [B,L] cuda, labels i64 [B] cuda.  Returns device tensors (loss_c, loss_d); no host sync."""
+    def _augment(self, wav, step_idx):
+        if not self.rawboost_algo:
+            return wav
+        # on-GPU RawBoost (data_utils_SSL.py:111-173; the call the reference leaves commented at oc_training.py:221)
+        from .RawBoost import rawboost_batch_device
+        from .oc_training import rawboost_args
+        return rawboost_batch_device(wav, self.rawboost_args or rawboost_args(), self.rawboost_algo, seed=self.seed, step=step_idx)
+
+    def _prefetch(self, next_wav, step_idx):
+        """Data stage of the next step (RawBoost + frozen front-end) on a side stream, concurrent with this step's back-end work.
+        The frozen front-end does not depend on the optimizer update, so results are identical to the sequential order."""
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=next_wav.device)
+        side = self._side
+        side.wait_stream(main)                      # inputs produced on the main stream; the feature buffer's previous reader has been enqueued
+        par = step_idx & 1
+        with torch.cuda.stream(side):
+            f = self.model.ssl_model.model.forward(self._augment(next_wav, step_idx), out_dtype=torch.float32)
+            if self._fbuf[par] is None or self._fbuf[par].shape != f.shape:
+                self._fbuf[par] = torch.empty_like(f)
+            self._fbuf[par].copy_(f)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        self._pref = (next_wav, self._fbuf[par], ready)
+
+    def step(self, wav, labels, next_wav=None):
+        """wav f32 [B,L] cuda, labels i64 [B] cuda.  Returns device tensors (loss_c, loss_d); no host sync.
+        next_wav: the batch of the following step() call (the same tensor object must then be passed as ``wav``); with a frozen
+        front-end its RawBoost + XLS-R features are computed concurrently with this step's back-end forward/backward/Adam."""
         be = self.be
-        if self.rawboost_algo:          # on-GPU RawBoost (data_utils_SSL.py:111-173; the call the reference leaves commented at oc_training.py:221)
-            from .RawBoost import rawboost_batch_device
-            from .oc_training import rawboost_args
-            wav = rawboost_batch_device(wav, self.rawboost_args or rawboost_args(), self.rawboost_algo, seed=self.seed, step=self.nstep)
+        raw_wav = wav
+        if self.train_frontend:
+            next_wav = None
+        if not (self._pref is not None and self._pref[0] is raw_wav):
+            wav = self._augment(wav, self.nstep)
+        step_idx = self.nstep
         self.nstep += 1
         if self.train_frontend:
             return self._step_finetune(wav, labels)
-        feats = self.model.ssl_model.model.forward(wav, out_dtype=torch.float32)
+        if self._pref is not None and self._pref[0] is raw_wav:
+            _, feats, ready = self._pref
+            torch.cuda.current_stream().wait_event(ready)
+        else:
+            feats = self.model.ssl_model.model.forward(wav, out_dtype=torch.float32)
+            if next_wav is not None:                # the front-end may return a buffer it reuses on every call: keep this step's copy
+                par = step_idx & 1
+                if self._fbuf[par] is None or self._fbuf[par].shape != feats.shape:
+                    self._fbuf[par] = torch.empty_like(feats)
+                self._fbuf[par].copy_(feats)
+                feats = self._fbuf[par]
+        self._pref = None
+        if next_wav is not None:
+            self._prefetch(next_wav, step_idx + 1)
         be.zero_grad()
         emb, logits = be.forward(feats, train=True, masks=self.dropout_masks)
         B = emb.shape[0]
