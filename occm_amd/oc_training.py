@@ -139,8 +139,15 @@ def main(argv=None):
         if sampler is not None:
             sampler.set_epoch(epoch)
         run_c = torch.zeros(1, device=device); run_d = torch.zeros(1, device=device)
-        for i, (inputs, labels) in enumerate(loader):
-            lc, ld = trainer.step(inputs.squeeze(0).to(device), labels.squeeze(0).to(device))
+        # one batch of look-ahead: the trainer runs the frozen front-end of batch i+1 on a side stream under batch i's back-end update
+        batches = ((inp.squeeze(0).to(device, non_blocking=True), lab.squeeze(0).to(device, non_blocking=True)) for inp, lab in loader)
+        cur = next(batches, None)
+        i = -1
+        while cur is not None:
+            i += 1
+            nxt = next(batches, None)
+            lc, ld = trainer.step(cur[0], cur[1], next_wav=None if nxt is None else nxt[0])
+            cur = nxt
             run_c += lc; run_d += ld                                    # stays on the GPU: no per-step host sync
             if i % 100 == 99 and rank == 0:
                 c, d = float(run_c) / (i + 1), float(run_d) / (i + 1)
