@@ -50,7 +50,7 @@ __device__ __forceinline__ float act_rt(int act, float v) {
     }
 }
 
-// Straight-line epilogue for the combinations the front-end launches thousands of times per step (alpha = 1, bias, no side
+// Straight-line epilogue for the combinations launched thousands of times per step (no side
 // tensor, activation none / GELU, residual none / f32): everything wave-uniform is a template parameter, the bias row is loaded
 // once per 16-column block instead of once per 16x16 block.  The generic gemm_epilogue below handles every other combination
 // with run-time switches; on the 128x128 tile that code executed ~1500 instructions per thread, which (with the workgroups of a
@@ -62,9 +62,11 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (breg) { bv[i] = breg[i]; continue; }
+        if (!a.bias) { bv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
         long long n = ncol0 + i * 16 + fq * 4; if (n > a.N - 4) n = a.N - 4;           // N % 4 == 0; out-of-range columns are never stored
         bv[i] = *reinterpret_cast<const f32x4*>(a.bias + cshift + n);
     }
+    const float alpha = a.alpha;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const long long m = mrow0 + j * 16 + fr;
@@ -75,7 +77,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
         for (int i = 0; i < 4; ++i) {
             const long long n = ncol0 + i * 16 + fq * 4;
             if (n >= a.N) continue;
-            f32x4 v = acc[i][j] + bv[i];
+            f32x4 v = acc[i][j] * alpha + bv[i];
             if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
             if (HASR) v += *reinterpret_cast<const f32x4*>(a.R + (roff + n) * 4);
             if (CBF) {
@@ -95,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
 template <int NJ>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
                                               const f32x4* breg = nullptr) {
-    if (a.alpha == 1.0f && a.bias && !a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU) && (!a.R || a.r_dtype == OCC_F32)) {
+    if (!a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU) && (!a.R || a.r_dtype == OCC_F32)) {
         const bool g = a.act == OCC_ACT_GELU, r = a.R != nullptr, cb = a.c_dtype != OCC_F32;      // wave-uniform: one scalar branch chain
         if (g) {
             if (r) { if (cb) gemm_epilogue_fast<NJ, true, true, true>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); else gemm_epilogue_fast<NJ, true, true, false>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); }
