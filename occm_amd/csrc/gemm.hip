@@ -37,6 +37,8 @@ struct GemmArgs {
     int group_m;              // >0: walk GROUP_M m-tiles per n-tile before moving on (L2-sized working set), 0: n fastest
     long long a_gstride, w_gstride, c_gstride;
     int ngroups;             // persistent kernel: groups folded into the tile id
+    int ksplit;              // > 1: the K range is cut into ksplit pieces handled by different workgroups, C += alpha*acc with f32 atomics
+    int slabs_per_split;
     int dbg;                 // ablation bits (timing experiments only, results wrong): 1 no loads in the K loop, 2 no MFMA, 4 no fragment reads
 };
 
@@ -55,18 +57,18 @@ __device__ __forceinline__ float act_rt(int act, float v) {
 // once per 16-column block instead of once per 16x16 block.  The generic gemm_epilogue below handles every other combination
 // with run-time switches; on the 128x128 tile that code executed ~1500 instructions per thread, which (with the workgroups of a
 // round reaching it together) was a third of a K = 1024 GEMM's run time.
-template <int NJ, bool GELU, bool HASR, bool CBF>
+template <int NJ, bool HASB, bool GELU, bool HASR, bool CBF>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
                                                    const f32x4* breg) {
     f32x4 bv[4];
+    if (HASB) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (breg) { bv[i] = breg[i]; continue; }
-        if (!a.bias) { bv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
-        long long n = ncol0 + i * 16 + fq * 4; if (n > a.N - 4) n = a.N - 4;           // N % 4 == 0; out-of-range columns are never stored
-        bv[i] = *reinterpret_cast<const f32x4*>(a.bias + cshift + n);
+        for (int i = 0; i < 4; ++i) {
+            if (breg) { bv[i] = breg[i]; continue; }
+            long long n = ncol0 + i * 16 + fq * 4; if (n > a.N - 4) n = a.N - 4;       // N % 4 == 0; out-of-range columns are never stored
+            bv[i] = *reinterpret_cast<const f32x4*>(a.bias + cshift + n);
+        }
     }
-    const float alpha = a.alpha;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const long long m = mrow0 + j * 16 + fr;
@@ -77,7 +79,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
         for (int i = 0; i < 4; ++i) {
             const long long n = ncol0 + i * 16 + fq * 4;
             if (n >= a.N) continue;
-            f32x4 v = acc[i][j] * alpha + bv[i];
+            f32x4 v = acc[i][j];
+            if (HASB) v += bv[i];
             if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
             if (HASR) v += *reinterpret_cast<const f32x4*>(a.R + (roff + n) * 4);
             if (CBF) {
@@ -92,20 +95,41 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
     }
 }
 
+// Split-K epilogue: C (f32) += alpha * acc with float atomics; used for weight-gradient GEMMs whose output has only a few dozen
+// tiles while K is the whole batch (the caller passes R == C, i.e. "accumulate"; the pieces add onto what C holds).
+template <int NJ>
+__device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long m = mrow0 + j * 16 + fr;
+        if (m >= a.M) continue;
+        float* crow = reinterpret_cast<float*>(a.C) + row_off(a.cmap, m) + cshift;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long n = ncol0 + i * 16 + fq * 4;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(crow + n + e, acc[i][j][e] * a.alpha);
+        }
+    }
+}
+
 // acc[i][j]: i = 16-column block of the wave's 64 output columns, j = 16-row block of its NJ*16 output rows;
 // mrow0 / ncol0 = first row / column of the wave's sub-tile.  A lane owns C[m][n..n+3].
 template <int NJ>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
                                               const f32x4* breg = nullptr) {
-    if (!a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU) && (!a.R || a.r_dtype == OCC_F32)) {
-        const bool g = a.act == OCC_ACT_GELU, r = a.R != nullptr, cb = a.c_dtype != OCC_F32;      // wave-uniform: one scalar branch chain
-        if (g) {
-            if (r) { if (cb) gemm_epilogue_fast<NJ, true, true, true>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); else gemm_epilogue_fast<NJ, true, true, false>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); }
-            else { if (cb) gemm_epilogue_fast<NJ, true, false, true>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); else gemm_epilogue_fast<NJ, true, false, false>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); }
-        } else {
-            if (r) { if (cb) gemm_epilogue_fast<NJ, false, true, true>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); else gemm_epilogue_fast<NJ, false, true, false>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); }
-            else { if (cb) gemm_epilogue_fast<NJ, false, false, true>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); else gemm_epilogue_fast<NJ, false, false, false>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); }
+    if (a.alpha == 1.0f && !a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU) && (!a.R || a.r_dtype == OCC_F32)) {
+        // wave-uniform flags -> one scalar branch chain into a straight-line instantiation
+        const int key = (a.bias ? 8 : 0) | (a.act == OCC_ACT_GELU ? 4 : 0) | (a.R ? 2 : 0) | (a.c_dtype != OCC_F32 ? 1 : 0);
+#define OCC_EPI(K, B, G, R, C) case K: gemm_epilogue_fast<NJ, B, G, R, C>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); break;
+        switch (key) {
+            OCC_EPI(0, false, false, false, false) OCC_EPI(1, false, false, false, true) OCC_EPI(2, false, false, true, false) OCC_EPI(3, false, false, true, true)
+            OCC_EPI(4, false, true, false, false) OCC_EPI(5, false, true, false, true) OCC_EPI(6, false, true, true, false) OCC_EPI(7, false, true, true, true)
+            OCC_EPI(8, true, false, false, false) OCC_EPI(9, true, false, false, true) OCC_EPI(10, true, false, true, false) OCC_EPI(11, true, false, true, true)
+            OCC_EPI(12, true, true, false, false) OCC_EPI(13, true, true, false, true) OCC_EPI(14, true, true, true, false) OCC_EPI(15, true, true, true, true)
         }
+#undef OCC_EPI
         return;
     }
 #pragma unroll
@@ -320,7 +344,7 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 // TMT = 128: 4 waves (2x2), 32 KiB LDS, 4 workgroups per CU.  TMT = 256: 8 waves (4x2) on a 256x128 tile, 48 KiB LDS,
 // 2 workgroups per CU: the same 16 waves per CU but 25 % fewer L2->LDS bytes per FLOP (the 128x128 tile moves one byte
 // per 64 FLOP, which is about what a CU can pull from L2 at its MFMA rate).
-template <int TMT>
+template <int TMT, bool SPLITK = false>
 __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma_kernel(const GemmArgs a) {
     constexpr int ES = 2, CE = 8, SLAB_K = 64;
     constexpr int NT = 2 * TMT;                 // threads
@@ -328,10 +352,12 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
     constexpr int XP = TMT / RPP, WP = TN / RPP;
     __shared__ uint4 lds[(TMT + TN) * CHUNKS];  // X rows then W rows: [row*8 + position]
     uint4* ldsX = lds; uint4* ldsW = lds + TMT * CHUNKS;
-    const int total = a.nbm * a.nbn;
+    const int total = a.nbm * a.nbn * (SPLITK ? a.ksplit : 1);
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
-    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int vid_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int kpart = SPLITK ? vid_all % a.ksplit : 0;                   // the pieces of one tile are neighbours (same XCD)
+    const int vid = SPLITK ? vid_all / a.ksplit : vid_all;
     int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
     if (a.group_m > 0) {                       // grouped order: GROUP_M m-tiles share each W panel while their X panels stay in L2
         const int per_group = a.group_m * a.nbn;
@@ -367,14 +393,16 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
         wsrc[i] = Wg + n * a.ldw * ES;
         wc[i] = pos ^ (row & 7);
     }
-    const int nslab = (int)(a.K / SLAB_K);
+    const int nslab_all = (int)(a.K / SLAB_K);
+    const int slab0 = SPLITK ? kpart * a.slabs_per_split : 0;
+    const int nslab = SPLITK ? (slab0 + a.slabs_per_split < nslab_all ? slab0 + a.slabs_per_split : nslab_all) : nslab_all;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
-    for (int slab = 0; slab < nslab; ++slab) {
+    for (int slab = slab0; slab < nslab; ++slab) {
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const long long k0 = (long long)slab * SLAB_K + xc[i] * CE;
@@ -409,7 +437,8 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
         }
         __syncthreads();
     }
-    gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+    if constexpr (SPLITK) gemm_epilogue_atomic<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+    else gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -954,6 +983,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     a.R = (const char*)d->R; a.rmap = to_rowmap(d->r_map); a.r_dtype = d->r_dtype;
     a.C = (char*)d->C; a.cmap = to_rowmap(d->c_map); a.c_dtype = d->c_dtype;
     a.act = d->act; a.alpha = d->alpha; a.aux = (unsigned short*)d->aux;
+    a.ksplit = 1; a.slabs_per_split = 0; a.ngroups = 1;
     a.dbg = g_dbg;
     a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
     // grouped tile order (8 m-tiles per W panel) measured +3 % on the N >= 3072 front-end GEMMs and +10 % at 4096^3, -2 % at N = 1024
@@ -986,8 +1016,28 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 3 || (variant == 1 && big))) {
         a.nbm = (int)nbm256;
         hipLaunchKernelGGL(gemm_bf16_dma_kernel<256>, dim3((unsigned)(nbm256 * a.nbn), (unsigned)ng), dim3(512), 0, s, a);
-    } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 1 || variant == 4))
-        hipLaunchKernelGGL(gemm_bf16_dma_kernel<128>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 1 || variant == 4)) {
+        // Few output tiles but a very long K (weight gradients: K = batch x frames): split K over workgroups, f32 atomics into C.
+        // Only for the accumulate form (R aliases C, f32, same row map), where adding the pieces onto C is the requested result.
+        const bool accumulate = d->R == d->C && d->c_dtype == OCC_F32 && d->r_dtype == OCC_F32 && !d->bias && d->act == OCC_ACT_NONE && !d->aux &&
+                                d->r_map.rows_per_batch == d->c_map.rows_per_batch && d->r_map.row_stride == d->c_map.row_stride &&
+                                d->r_map.batch_stride == d->c_map.batch_stride && d->r_map.rows_per_line == d->c_map.rows_per_line &&
+                                d->r_map.line_stride == d->c_map.line_stride;
+        const long long nslab = d->K / 64, want = 4ll * cu_count();
+        long long split = 1;
+        if (accumulate && total * ng < want / 2 && nslab >= 32 && variant == 1) {
+            split = occ_cdiv(want, total * ng);
+            if (split > nslab / 8) split = nslab / 8;
+            if (split < 1) split = 1;
+        }
+        if (split > 1) {
+            a.slabs_per_split = (int)occ_cdiv(nslab, split);
+            a.ksplit = (int)occ_cdiv(nslab, a.slabs_per_split);
+            a.R = nullptr;
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<128, true>), dim3((unsigned)(total * a.ksplit), (unsigned)ng), dim3(THREADS), 0, s, a);
+        } else
+            hipLaunchKernelGGL(gemm_bf16_dma_kernel<128>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    }
     else if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<1>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else if (d->ab_dtype == OCC_F32_AS_BF16 && d->N <= 64 && g_variant != 14) {        // narrow outputs: 128x64 tile
         a.nbn = 1;

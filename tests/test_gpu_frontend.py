@@ -197,3 +197,17 @@ def test_bf16_gemm_kernel_family_agrees(variant):
     finally:
         lib().occ_gemm_variant(prev)
     assert lib().occ_gemm_variant(-1) == prev
+
+
+@pytest.mark.parametrize("N,Kd,M", [(128, 128, 8192), (512, 1536, 20480), (1024, 1024, 12736), (200, 136, 4096)])
+def test_gemm_split_k_accumulate(N, Kd, M):
+    """Weight-gradient form C[N,Kd] += A[N,M] . B[Kd,M]^T with few output tiles and a long reduction: occ_gemm splits K over
+    workgroups and adds the pieces with f32 atomics (R aliases C = accumulate).  Must equal the one-workgroup result."""
+    from occm_amd import ops
+    a = _r(N, M, seed=1).bfloat16(); b = _r(Kd, M, seed=2).bfloat16()
+    c0 = _r(N, Kd, seed=3)
+    C = c0.clone().cuda()
+    ops.gemm_raw(N, Kd, M, a.cuda(), ops.rowmap(N, 0, M), b.cuda(), M, C, ops.rowmap(N, 0, Kd), ops.OCC_F32, ops.OCC_BF16, R=C, r_map=ops.rowmap(N, 0, Kd),
+                 r_dtype=ops.OCC_F32, alpha=0.5)
+    ref = c0.double() + 0.5 * (a.double() @ b.double().T)
+    torch.testing.assert_close(C.cpu().double(), ref, rtol=1e-4, atol=2e-5 * float(ref.abs().max()) + 1e-4)
