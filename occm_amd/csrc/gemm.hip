@@ -1023,9 +1023,12 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
                                 d->r_map.rows_per_batch == d->c_map.rows_per_batch && d->r_map.row_stride == d->c_map.row_stride &&
                                 d->r_map.batch_stride == d->c_map.batch_stride && d->r_map.rows_per_line == d->c_map.rows_per_line &&
                                 d->r_map.line_stride == d->c_map.line_stride;
-        const long long nslab = d->K / 64, want = 4ll * cu_count();
+        // measured (scripts/bench_wgrad.py): the atomics are expensive, so split only up to one workgroup per CU (two for the
+        // conv-stack gradients whose K is hundreds of thousands): 1024x1024x12736 200 -> 104 us, 512x1536x409536 7817 -> 1164 us
+        static const long long per_cu = getenv("OCC_GEMM_SPLIT_PER_CU") ? atoll(getenv("OCC_GEMM_SPLIT_PER_CU")) : -1;
+        const long long nslab = d->K / 64, want = (per_cu >= 0 ? per_cu : (nslab >= 2048 ? 2 : 1)) * cu_count();
         long long split = 1;
-        if (accumulate && total * ng < want / 2 && nslab >= 32 && variant == 1) {
+        if (accumulate && total * ng <= want / 2 && nslab >= 32 && variant == 1) {
             split = occ_cdiv(want, total * ng);
             if (split > nslab / 8) split = nslab / 8;
             if (split < 1) split = 1;
