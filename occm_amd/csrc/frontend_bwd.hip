@@ -363,8 +363,9 @@ __global__ void gelu_bwd_rows_kernel(const float* __restrict__ dy, const unsigne
 // Backward of the fused first conv block (Conv1d(1->512,k,stride) + LayerNorm + GELU): everything is recomputed from the
 // waveform, nothing was saved.  One wave per frame, lane = 8 channels; weight / bias / LayerNorm gradients are reduced in
 // registers over the wave's frames, then over the 4 waves through LDS, then one set of atomics per workgroup.
-constexpr int C0B_FRAMES = 256, C0B_MAXK = 16;
-template <typename TD>
+constexpr int C0B_FRAMES = 256, C0B_MAXK = 16;   // C0B_MAXK: largest supported tap count
+// KT = compile-time tap count held in registers (weights + their gradients: 16 * KT VGPRs per lane); KT = 10 is XLS-R's first conv.
+template <typename TD, int KT>
 __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w, const float* __restrict__ bias,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, const TD* __restrict__ dact,
                                                        float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -377,24 +378,24 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < nsamp; i += 256) { const int g = f0 * stride + i; smp[i] = g < L ? wb[g] : 0.f; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = lane * 8;
-    float wr[8][C0B_MAXK], br[8], gr[8], ber[8];
-    float gw[8][C0B_MAXK], gb[8], gg[8], gbe[8];
+    float wr[8][KT], br[8], gr[8], ber[8];
+    float gw[8][KT], gb[8], gg[8], gbe[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         br[e] = bias[c0 + e]; gr[e] = gamma[c0 + e]; ber[e] = beta[c0 + e];
         gb[e] = 0.f; gg[e] = 0.f; gbe[e] = 0.f;
 #pragma unroll
-        for (int t = 0; t < C0B_MAXK; ++t) { wr[e][t] = t < k ? w[(size_t)(c0 + e) * k + t] : 0.f; gw[e][t] = 0.f; }
+        for (int t = 0; t < KT; ++t) { wr[e][t] = t < k ? w[(size_t)(c0 + e) * k + t] : 0.f; gw[e][t] = 0.f; }
     }
     __syncthreads();
     for (int fi = 0; fi < C0B_FRAMES / 4; ++fi) {
         const int fl = wave * (C0B_FRAMES / 4) + fi, f = f0 + fl;
         if (f >= Tout) break;
-        float acc[8], xs[C0B_MAXK];
+        float acc[8], xs[KT];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = br[e];
 #pragma unroll
-        for (int t = 0; t < C0B_MAXK; ++t) {
+        for (int t = 0; t < KT; ++t) {
             xs[t] = t < k ? smp[fl * stride + t] : 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = fmaf(wr[e][t], xs[t], acc[e]);
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
             const float dp = rstd * (dv[e] - s1 - xh[e] * s2);
             gb[e] += dp;
 #pragma unroll
-            for (int t = 0; t < C0B_MAXK; ++t) gw[e][t] = fmaf(dp, xs[t], gw[e][t]);
+            for (int t = 0; t < KT; ++t) gw[e][t] = fmaf(dp, xs[t], gw[e][t]);
         }
     }
     // reduce over the 4 waves: layout per wave [512][k+3] = (dw[k], dbias, dgamma, dbeta)
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
         float* r = red + (size_t)(wave - 1) * 512 * rs;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            for (int t = 0; t < k; ++t) r[(c0 + e) * rs + t] = gw[e][t];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) if (t < k) r[(c0 + e) * rs + t] = gw[e][t];      // static index: a run-time index would push gw to scratch
             r[(c0 + e) * rs + k] = gb[e]; r[(c0 + e) * rs + k + 1] = gg[e]; r[(c0 + e) * rs + k + 2] = gbe[e];
         }
     }
@@ -443,7 +445,9 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
-            for (int t = 0; t < k; ++t) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                if (t >= k) continue;
                 float v = gw[e][t];
                 for (int w2 = 0; w2 < 3; ++w2) v += red[(size_t)w2 * 512 * rs + c * rs + t];
                 atomicAdd(dw + (size_t)c * k + t, v);
@@ -597,15 +601,14 @@ int occ_conv0_ln_gelu_bwd(const float* wav, const float* w, const float* bias, c
     const dim3 grid((unsigned)occ_cdiv(Tout, C0B_FRAMES), (unsigned)B), block(256);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (dact_dtype == OCC_F32) {
-        e = hipFuncSetAttribute((const void*)conv0_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) { occ_set_error("occ_conv0_ln_gelu_bwd: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
-        hipLaunchKernelGGL(conv0_bwd_kernel<float>, grid, block, shm, s, wav, w, bias, gamma, beta, (const float*)dact, dw, dbias, dgamma, dbeta, (int)L, (int)Tout, (int)k, (int)stride, eps);
-    } else {
-        e = hipFuncSetAttribute((const void*)conv0_bwd_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) { occ_set_error("occ_conv0_ln_gelu_bwd: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
-        hipLaunchKernelGGL(conv0_bwd_kernel<unsigned short>, grid, block, shm, s, wav, w, bias, gamma, beta, (const unsigned short*)dact, dw, dbias, dgamma, dbeta, (int)L, (int)Tout, (int)k, (int)stride, eps);
-    }
+#define OCC_C0B(TD, KT, CAST)                                                                                                              \
+    e = hipFuncSetAttribute((const void*)conv0_bwd_kernel<TD, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                       \
+    if (e != hipSuccess) { occ_set_error("occ_conv0_ln_gelu_bwd: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }                              \
+    hipLaunchKernelGGL((conv0_bwd_kernel<TD, KT>), grid, block, shm, s, wav, w, bias, gamma, beta, (const TD*)dact, dw, dbias, dgamma, dbeta,   \
+                       (int)L, (int)Tout, (int)k, (int)stride, eps)
+    if (dact_dtype == OCC_F32) { if (k <= 10) { OCC_C0B(float, 10, 0); } else { OCC_C0B(float, C0B_MAXK, 0); } }
+    else { if (k <= 10) { OCC_C0B(unsigned short, 10, 0); } else { OCC_C0B(unsigned short, C0B_MAXK, 0); } }
+#undef OCC_C0B
     OCC_LAUNCH_CHECK("occ_conv0_ln_gelu_bwd");
     return OCC_OK;
 }

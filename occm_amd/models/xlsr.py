@@ -689,7 +689,7 @@ class XlsrFullFineTuner(XlsrFineTuner):
         K.fill(self.pos_dw.view(-1), 0.0)
         for g in range(G):
             K.gemm_tn(M, cg, Kp * cg, du_in + g * cg * 2, dmap, xpad.data_ptr() + g * cg * 2, dmap, self.pos_dw[g], Kp * cg, b_seg=(Kp, cg, D),
-                      colsum_out=self.mg["pos.b"][g * cg:(g + 1) * cg], a_bf16=True, b_bf16=True)
+                      colsum_out=self.mg["pos.b"][g * cg:(g + 1) * cg], a_bf16=True, b_bf16=True, bf16_mfma=True)   # operands are bf16 already: same products
         check(lib().occ_weight_norm_bwd(ptr(self.mp["pos.v"]), ptr(self.mp["pos.g"]), ptr(self.pos_norms), ptr(self.pos_dw), ptr(self.mg["pos.v"]),
                                         ptr(self.mg["pos.g"]), D, cg, Kp, G, stream_ptr()), "occ_weight_norm_bwd")
         xm = rowmap(M, 0, D)
