@@ -278,9 +278,12 @@ int occ_layernorm(const void* x, int x_dtype, void* y, int y_dtype, const float*
 int occ_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const float* gamma,
                       const float* beta, void* out, int out_dtype, int64_t B, int64_t L, int64_t Tout,
                       int64_t C, int64_t k, int64_t stride, float eps, void* stream);
-/* Multi-head self-attention core softmax(Q.K^T).V for short sequences (T <= 1024), head_dim 64/80.
- * qkv: [B*T, 3*D] rows (q | k | v); scores are scale * q.k (fairseq scales q by hd^-0.5); out: [B*T, D].  */
-/* lse (optional, f32 [B*H, T], bf16 / head_dim 64 / T <= 256 path only): log2-sum-exp2 of the scaled scores, kept for backward. */
+/* Multi-head self-attention core softmax(Q.K^T).V (un-masked, as the reference runs it: fairseq MultiheadAttention reached from
+ * sslassist.py:48; evaluation scores un-padded batch-1 utterances of any length, oc_classifier.py:185-193).
+ * qkv: [B*T, 3*D] rows (q | k | v); scores are scale * q.k (fairseq scales q by hd^-0.5); out: [B*T, D].
+ * bf16, head_dim 64: MFMA kernels, any T (T <= 256: whole key set on chip; longer: keys streamed in blocks of 128 with the
+ * online-softmax recurrence).  f32 (parity path) or other head dims: LDS kernel, T limited by 160 KiB of LDS (~300 at hd 64).
+ * lse (optional, f32 [B*H, T], MFMA kernels only): log2-sum-exp2 of the scaled scores, kept for backward.                */
 int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd,
                   int64_t ld_qkv, int64_t ld_out, float scale, float* lse, void* stream);
 /* ---- backward of the transformer encoder (fine-tuning; autograd of fairseq's pre-LN TransformerSentenceEncoderLayer) ---- */

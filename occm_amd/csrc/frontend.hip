@@ -339,6 +339,130 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
     }
 }
 
+// Long sequences (evaluation utterances: T is whatever the audio gives): the same fragment scheme, keys streamed in blocks of
+// 128 through LDS with the online-softmax recurrence (running max m and sum l per query; the O accumulators are rescaled by
+// 2^(m_old - m_new) when a block raises the max).  The reference scores un-padded, un-masked batch-1 utterances
+// (oc_classifier.py:185-193); nothing here depends on T except the loop count.
+__global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
+                                                                 int Tn, int H, long long ld_qkv, long long ld_out, float scale, float* __restrict__ lse) {
+    constexpr int NP = 4, NK = NP * 32, VS = NK + 4;
+    __shared__ uint4 Ks[NK * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[64 * VS];
+    const int D = H * 64;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int q0 = blockIdx.y * 64;
+    const unsigned short* base = qkv + (size_t)b * Tn * ld_qkv + (size_t)h * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int qrow = q0 + wave * 16 + fr;
+    const bool active = q0 + wave * 16 < Tn;                 // wave-uniform; inactive waves still help staging and hit the barriers
+    const int qld = qrow < Tn ? qrow : Tn - 1;
+    uint4 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = *reinterpret_cast<const uint4*>(base + (size_t)qld * ld_qkv + s * 32 + g * 8);
+    const float c = scale * 1.44269504088896340736f;
+    float m_run = -3.0e38f, l_run = 0.f;
+    af32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (af32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < Tn; k0 += NK) {
+        __syncthreads();                                     // previous block fully consumed
+        for (int idx = threadIdx.x; idx < NK * 8; idx += 256) {
+            const int kl = idx >> 3, ch = idx & 7, key = k0 + kl;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (key < Tn) {
+                kv = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + D + ch * 8);
+                vv = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + 2 * D + ch * 8);
+            }
+            Ks[kl * 8 + (ch ^ (kl & 7))] = kv;
+            const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Vt[(ch * 8 + 2 * e) * VS + kl] = (unsigned short)(w[e] & 0xffff);
+                Vt[(ch * 8 + 2 * e + 1) * VS + kl] = (unsigned short)(w[e] >> 16);
+            }
+        }
+        __syncthreads();
+        if (!active) continue;
+        af32x4 sc[2 * NP];
+#pragma unroll
+        for (int t = 0; t < 2 * NP; ++t) {
+            sc[t] = (af32x4){0.f, 0.f, 0.f, 0.f};
+            const int kr = t * 16 + fr;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 kf = Ks[kr * 8 + ((s * 4 + g) ^ (kr & 7))];
+                sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<abf16x8*>(&kf), *reinterpret_cast<abf16x8*>(&qf[s]), sc[t], 0, 0, 0);
+            }
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < 2 * NP; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + t * 16 + g * 4 + r;
+                const float v = key < Tn ? sc[t][r] * c : -3.0e38f;
+                sc[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);                // every block holds at least one real key, so m_new is finite
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * NP; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sc[t][r] - m_new);
+                sc[t][r] = pv;
+                sum += pv;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                        // O rows are queries 4g + r; their factor lives in the lane with fr == 4g + r
+            const float a_q = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt][r] *= a_q;
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            unsigned pw[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                pw[e] = (unsigned)f32_to_bf16_bits(sc[2 * u][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u][2 * e + 1]) << 16);
+                pw[2 + e] = (unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e + 1]) << 16);
+            }
+            uint4 pf = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const unsigned short* vr = Vt + (dt * 16 + fr) * VS + u * 32 + g * 4;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+                uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<abf16x8*>(&pf), *reinterpret_cast<abf16x8*>(&vf), oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+    const float inv = 1.0f / l_run;
+    if (lse && g == 0 && qrow < Tn) lse[(size_t)bh * Tn + qrow] = m_run + __builtin_amdgcn_logf(l_run);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ql = g * 4 + r;
+        const float iv = __shfl(inv, ql, 64);
+        const int q = q0 + wave * 16 + ql;
+        if (q < Tn) {
+            unsigned short* orow = out + ((size_t)b * Tn + q) * ld_out + (size_t)h * 64 + fr;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) orow[dt * 16] = f32_to_bf16_bits(oacc[dt][r] * iv);
+        }
+    }
+}
+
 template <int NP>
 void launch_attention_mfma(const void* qkv, void* out, int B, int T, int H, long long ld_qkv, long long ld_out, float scale, float* lse, hipStream_t s) {
     const dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64)), block(256);
@@ -386,7 +510,7 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
                   float scale, float* lse, void* stream) {
     OCC_CHECK_ARG(qkv && out, "occ_attention: null pointer");
     OCC_CHECK_ARG(B >= 1 && T >= 1 && H >= 1 && hd >= 8 && hd <= 128, "occ_attention: bad shape");
-    OCC_CHECK_ARG(T <= 1024, "occ_attention: T=%ld exceeds the short-sequence limit 1024", (long)T);
+    OCC_CHECK_ARG(T <= (1 << 20), "occ_attention: T=%ld is not a plausible frame count", (long)T);
     OCC_CHECK_ARG(ld_qkv >= 3 * H * hd && ld_out >= H * hd, "occ_attention: leading dimensions too small");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == OCC_BF16 && hd == 64 && T <= 256 && ld_qkv % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) {
@@ -399,7 +523,14 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
         OCC_LAUNCH_CHECK("occ_attention(mfma)");
         return OCC_OK;
     }
-    OCC_CHECK_ARG(!lse, "occ_attention: the log-sum-exp output needs the bf16 / head_dim 64 / T <= 256 MFMA path");
+    if (dtype == OCC_BF16 && hd == 64 && ld_qkv % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) {       // any T: keys streamed in blocks
+        const dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64)), block(256);
+        hipLaunchKernelGGL(attention_mfma_long_kernel, grid, block, 0, s, (const unsigned short*)qkv, (unsigned short*)out, (int)T, (int)H, (long long)ld_qkv,
+                           (long long)ld_out, scale, lse);
+        OCC_LAUNCH_CHECK("occ_attention(mfma, long)");
+        return OCC_OK;
+    }
+    OCC_CHECK_ARG(!lse, "occ_attention: the log-sum-exp output needs the bf16 / head_dim 64 MFMA path");
     const size_t shm = ((size_t)2 * T * (hd + 1) + 4 * T + 4 * hd) * sizeof(float);
     OCC_CHECK_ARG(shm <= 160 * 1024, "occ_attention: T=%ld hd=%ld needs %zu B of LDS (> 160 KiB)", (long)T, (long)hd, shm);
     const int qsplit = 4;

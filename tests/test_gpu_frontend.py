@@ -211,3 +211,53 @@ def test_gemm_split_k_accumulate(N, Kd, M):
                  r_dtype=ops.OCC_F32, alpha=0.5)
     ref = c0.double() + 0.5 * (a.double() @ b.double().T)
     torch.testing.assert_close(C.cpu().double(), ref, rtol=1e-4, atol=2e-5 * float(ref.abs().max()) + 1e-4)
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 650, 16), (2, 1001, 2), (1, 257, 3), (1, 384, 1), (1, 3000, 1)])
+def test_attention_long_sequences(B, T, H):
+    """T > 256 (evaluation utterances of any length): keys streamed in blocks of 128 with the online-softmax recurrence."""
+    from occm_amd import ops
+    hd, D = 64, H * 64
+    qkv = _r(B * T, 3 * D, seed=31).bfloat16()
+    q, k, v = [t.float().view(B, T, H, hd).transpose(1, 2) for t in qkv.split(D, dim=1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B * T, D)
+    out = ops.attention(qkv.cuda(), B, T, H, hd, hd ** -0.5)
+    torch.testing.assert_close(out.cpu().float(), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_attention_long_forced_rescale():
+    """A key far into the sequence that dominates one query's softmax forces the running-max rescale branch (the accumulators
+    built from the first blocks must be scaled down by 2^(m_old - m_new)); random data alone rarely moves the max by much."""
+    from occm_amd import ops
+    B, T, H, hd = 1, 700, 2, 64
+    D = H * hd
+    qkv = _r(B * T, 3 * D, seed=33).view(T, 3, H, hd)
+    qkv[5, 0, 0] = 3.0 * torch.ones(hd)                   # query 5 of head 0 ...
+    qkv[600, 1, 0] = 4.0 * torch.ones(hd)                 # ... matches key 600 (5th block): score 768 * scale = 96 >> the rest
+    qkv[300, 1, 1] = -qkv[9, 0, 1] * 2.0                  # and a strongly negative one elsewhere
+    qkv = qkv.reshape(T, 3 * D).bfloat16()
+    q, k, v = [t.float().view(B, T, H, hd).transpose(1, 2) for t in qkv.split(D, dim=1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B * T, D)
+    lse = torch.empty(B * H * T, device="cuda")
+    out = ops.attention(qkv.cuda(), B, T, H, hd, hd ** -0.5, lse=lse)
+    torch.testing.assert_close(out.cpu().float(), ref, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(out.cpu().float()[5, :hd], v[0, 0, 600], rtol=1e-2, atol=1e-2)   # that query's output is (almost) exactly v[600]
+    s2 = q @ k.transpose(-1, -2) * hd ** -0.5 * 1.4426950408889634          # scores in the log2 domain, as the kernel keeps them
+    ref_lse = torch.log2(torch.exp2(s2 - s2.amax(-1, keepdim=True)).sum(-1)) + s2.amax(-1)
+    torch.testing.assert_close(lse.cpu().view(B, H, T), ref_lse, rtol=1e-3, atol=2e-2)
+
+
+def test_frontend_long_utterance_matches_oracle():
+    """13 s of audio (T = 649 frames) through the bf16 front-end vs the fp32 oracle (same bar as the 4 s bf16 test)."""
+    from oracle import xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.models import xlsr
+    rcfg, cfg = _small_cfgs()
+    p = fill_like(xlsr_ref.param_shapes(rcfg), seed=3)
+    wav = 0.1 * _r(1, 208000, seed=5)
+    with torch.no_grad():
+        ref = xlsr_ref.extract_feat(wav, p, rcfg)
+    out = xlsr.XlsrFrontend(p, cfg, dtype=torch.bfloat16).forward(wav.cuda(), out_dtype=torch.float32).cpu()
+    assert out.shape == ref.shape and out.shape[1] == 649
+    err = (out - ref).abs()
+    assert float(err.max()) < 6e-2 and float(err.mean()) < 1e-2, (float(err.max()), float(err.mean()))
