@@ -542,7 +542,7 @@ int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
     const int nit = (int)((C + 511) / 512);
     OCC_CHECK_ARG(nit <= 2 || !gelu, "occ_layernorm_bwd: fused GELU supports C <= 1024");
     hipStream_t s = (hipStream_t)stream;
-    RowMapI bm{rows, 0, C, 0, 0};
+    RowMapI bm = occ_make_rowmap(rows, 0, C, 0, 0);
     if (dx_bf16_map) { OCC_CHECK_ARG(dx_bf16_map->rows_per_batch >= 1 && dx_bf16_map->row_stride % 8 == 0 && dx_bf16_map->batch_stride % 8 == 0, "occ_layernorm_bwd: bad bf16 row map"); bm = to_rowmap(*dx_bf16_map); }
 #define OCC_LNB(TD, TXX, N, G) hipLaunchKernelGGL((layernorm_bwd_kernel<TD, TXX, N, G>), dim3((unsigned)blocks), dim3(256), 0, s, (const TD*)dy, (const TXX*)x, gamma, beta, dres, dx, (unsigned short*)dx_bf16, bm, dgamma, dbeta, (long long)rows, (int)C, eps)
 #define OCC_LNB_N(TD, TXX, G) do { if (nit == 1) OCC_LNB(TD, TXX, 1, G); else if (nit == 2) OCC_LNB(TD, TXX, 2, G); else if (nit == 3) OCC_LNB(TD, TXX, 3, false); else OCC_LNB(TD, TXX, 4, false); } while (0)

@@ -103,13 +103,25 @@ template <int ACT> __device__ __forceinline__ float occ_apply_act(float x) {
 static inline int64_t occ_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // device-side copy of occ_rowmap (element offsets)
-struct RowMapI { long long rpb, bstride, rstride, rpl, lstride; };
-static inline RowMapI to_rowmap(const occ_rowmap& m) { return RowMapI{m.rows_per_batch, m.batch_stride, m.row_stride, m.rows_per_line, m.line_stride}; }
+// Row indices and rows_per_batch / rows_per_line fit 32 bits on every path.  The two divisions of a row index are done by
+// multiplication with a host-computed magic number (floor(2^64 / d) + 1: exact for 32-bit dividends), and the only branch left
+// is on rows_per_line, which is wave-uniform -- a kernel that maps four rows per thread per slab (gemm_tn) no longer runs
+// divergent code paths or 32-bit division sequences in its inner loop.
+struct RowMapI { long long rpb, bstride, rstride, rpl, lstride; unsigned long long mg_rpb, mg_rpl; };
+static inline unsigned long long occ_div_magic(long long d) { return d <= 1 ? 0ull : (~0ull) / (unsigned long long)d + 1ull; }   // 0: divide by one
+static inline RowMapI occ_make_rowmap(long long rpb, long long bstride, long long rstride, long long rpl, long long lstride) {
+    return RowMapI{rpb, bstride, rstride, rpl, lstride, occ_div_magic(rpb), occ_div_magic(rpl)};
+}
+static inline RowMapI to_rowmap(const occ_rowmap& m) { return occ_make_rowmap(m.rows_per_batch, m.batch_stride, m.row_stride, m.rows_per_line, m.line_stride); }
+__device__ __forceinline__ unsigned occ_fastdiv(unsigned n, unsigned long long magic) {
+    return magic ? (unsigned)__umul64hi((unsigned long long)n, magic) : n;
+}
 __device__ __forceinline__ long long row_off(const RowMapI& m, long long row) {
-    if (row < m.rpb && m.rpl == 0) return row * m.rstride;              // plain matrix: no division at all
-    // rows and rows_per_batch fit 32 bits everywhere on this path: unsigned 32-bit division is ~4x cheaper than 64-bit
-    const unsigned rw = (unsigned)row, rpb = (unsigned)m.rpb;
-    const unsigned b = rw / rpb, r = rw - b * rpb;
-    if (m.rpl > 0) { const unsigned rpl = (unsigned)m.rpl, l = r / rpl; return b * m.bstride + l * m.lstride + (long long)(r - l * rpl) * m.rstride; }
+    const unsigned rw = (unsigned)row;
+    const unsigned b = occ_fastdiv(rw, m.mg_rpb), r = rw - b * (unsigned)m.rpb;
+    if (m.rpl > 0) {
+        const unsigned l = occ_fastdiv(r, m.mg_rpl);
+        return b * m.bstride + l * m.lstride + (long long)(r - l * (unsigned)m.rpl) * m.rstride;
+    }
     return b * m.bstride + (long long)r * m.rstride;
 }
