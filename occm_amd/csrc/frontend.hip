@@ -240,28 +240,39 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
     __shared__ __attribute__((aligned(16))) unsigned short Vt[64 * VS];
     const int D = H * 64;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int q0 = blockIdx.y * 64;
+    const int qchunk = (((Tn + 15) / 16 + gridDim.y - 1) / gridDim.y) * 16;      // queries of this workgroup: a multiple of 16
+    const int q_begin = blockIdx.y * qchunk, q_end = q_begin + qchunk < Tn ? q_begin + qchunk : Tn;
     const unsigned short* base = qkv + (size_t)b * Tn * ld_qkv + (size_t)h * 64;
-    for (int idx = threadIdx.x; idx < NK * 8; idx += 256) {
-        const int key = idx >> 3, ch = idx & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < Tn) {
-            kv = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + D + ch * 8);
-            vv = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + 2 * D + ch * 8);
-        }
-        Ks[key * 8 + (ch ^ (key & 7))] = kv;
-        const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+    {   // all 2*NP loads of this thread are issued before the first LDS write: one exposed memory latency instead of NP
+        uint4 kv[NP], vv[NP];
+        const int ch = threadIdx.x & 7;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            Vt[(ch * 8 + 2 * e) * VS + key] = (unsigned short)(w[e] & 0xffff);
-            Vt[(ch * 8 + 2 * e + 1) * VS + key] = (unsigned short)(w[e] >> 16);
+        for (int it = 0; it < NP; ++it) {
+            const int key = it * 32 + (threadIdx.x >> 3);
+            const int kc = key < Tn ? key : Tn - 1;
+            kv[it] = *reinterpret_cast<const uint4*>(base + (size_t)kc * ld_qkv + D + ch * 8);
+            vv[it] = *reinterpret_cast<const uint4*>(base + (size_t)kc * ld_qkv + 2 * D + ch * 8);
+            if (key >= Tn) { kv[it] = make_uint4(0, 0, 0, 0); vv[it] = kv[it]; }
+        }
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int key = it * 32 + (threadIdx.x >> 3);
+            Ks[key * 8 + (ch ^ (key & 7))] = kv[it];
+            const unsigned w[4] = {vv[it].x, vv[it].y, vv[it].z, vv[it].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Vt[(ch * 8 + 2 * e) * VS + key] = (unsigned short)(w[e] & 0xffff);
+                Vt[(ch * 8 + 2 * e + 1) * VS + key] = (unsigned short)(w[e] >> 16);
+            }
         }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, g = lane >> 4;
-    const int qrow = q0 + wave * 16 + fr;
-    if (q0 + wave * 16 >= Tn) return;                       // whole wave out of range (wave-uniform)
+    // K / V of the head are staged once per workgroup; each wave then walks 16-query blocks (staging was ~2/3 of the run time
+    // when every 64 queries re-staged the head)
+    for (int q0 = q_begin + wave * 16; q0 < q_end; q0 += 64) {
+    const int qrow = q0 + fr;
     const int qld = qrow < Tn ? qrow : Tn - 1;
     uint4 qf[2];
 #pragma unroll
@@ -330,12 +341,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
     for (int r = 0; r < 4; ++r) {
         const int ql = g * 4 + r;
         const float iv = __shfl(inv, ql, 64);
-        const int q = q0 + wave * 16 + ql;
+        const int q = q0 + ql;
         if (q < Tn) {
             unsigned short* orow = out + ((size_t)b * Tn + q) * ld_out + (size_t)h * 64 + fr;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) orow[dt * 16] = f32_to_bf16_bits(oacc[dt][r] * iv);
         }
+    }
     }
 }
 
@@ -465,7 +477,10 @@ __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned
 
 template <int NP>
 void launch_attention_mfma(const void* qkv, void* out, int B, int T, int H, long long ld_qkv, long long ld_out, float scale, float* lse, hipStream_t s) {
-    const dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64)), block(256);
+    // one workgroup per head when there are enough heads to fill the chip (2 workgroups per CU fit), else split the queries
+    int ysplit = 1;
+    while ((long long)B * H * ysplit < 512 && ysplit * 64 < T) ysplit *= 2;
+    const dim3 grid((unsigned)(B * H), (unsigned)ysplit), block(256);
     hipLaunchKernelGGL(attention_mfma_kernel<NP>, grid, block, 0, s, (const unsigned short*)qkv, (unsigned short*)out, T, H, ld_qkv, ld_out, scale, lse);
 }
 
