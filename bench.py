@@ -141,6 +141,7 @@ def main():
     from occm_amd.trainer import OcTrainer
     require_gpu()
     rank, world, local = parallel.init_from_env()
+    local = local % max(1, torch.cuda.device_count())       # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = xlsr.XlsrConfig.xlsr_300m()
@@ -177,7 +178,8 @@ def main():
         split_forward()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: with world > 1 the RCCL watchdog thread polls events while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             split_forward()
 
         def replay_forward(w, out_dtype=None, taps=None):
