@@ -528,7 +528,9 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
     OCC_CHECK_ARG(T <= (1 << 20), "occ_attention: T=%ld is not a plausible frame count", (long)T);
     OCC_CHECK_ARG(ld_qkv >= 3 * H * hd && ld_out >= H * hd, "occ_attention: leading dimensions too small");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == OCC_BF16 && hd == 64 && T <= 256 && ld_qkv % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) {
+    // T > 128: the streaming kernel (98 VGPRs, 33 KiB LDS) beats holding all keys on chip (384 registers at T = 199: one wave per
+    // SIMD) -- 27.1 vs 29.4 us at B = 32, T = 199, 16 heads
+    if (dtype == OCC_BF16 && hd == 64 && T <= 128 && ld_qkv % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) {
         const int np = (int)((T + 31) / 32);
         if (np <= 1) launch_attention_mfma<1>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
         else if (np <= 2) launch_attention_mfma<2>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
