@@ -185,6 +185,36 @@ def gen_aasist():
     print("aasist.npz", len(out))
 
 
+def gen_train_steps():
+    """Three optimizer steps of the reference's own loop body (oc_training.py:363-385: zero_grad -> forward -> 0.1 c + 0.9 d ->
+    backward -> Adam) on fixed features, dropout p forced to 0: per-step losses and a few parameters / buffers afterwards."""
+    cl = sys.modules.get("ref_custom_loss") or _load("ref_custom_loss", os.path.join(REF, "losses", "custom_loss.py"))
+    m = _build_ref_amodel()
+    m.load_state_dict(fill_like(aasist_ref.param_shapes(), seed=0), strict=True)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    labels = (torch.arange(12) >= 6).long()
+    out = {"loss_c": [], "loss_d": []}
+    for step in range(3):
+        feats = torch.randn(12, 199, 1024, generator=torch.Generator().manual_seed(200 + step))
+        opt.zero_grad()
+        emb, logit = m(feats)
+        lc, ld = cl.compactness_loss(emb), cl.descriptiveness_loss(logit, labels)
+        (0.1 * lc + 0.9 * ld).backward()
+        opt.step()
+        out["loss_c"].append(float(lc)); out["loss_d"].append(float(ld))
+    sd = m.state_dict()
+    for k in ("out_layer.weight", "out_layer.bias", "LL.bias", "pos_S", "master1", "first_bn.running_mean", "first_bn.num_batches_tracked",
+              "encoder.5.0.conv2.bias", "GAT_layer_T.att_weight"):
+        out["p_" + k] = sd[k].numpy().copy()
+    out["loss_c"] = np.array(out["loss_c"]); out["loss_d"] = np.array(out["loss_d"])
+    np.savez_compressed(os.path.join(OUT, "train_steps.npz"), **out)
+    print("train_steps.npz", out["loss_c"], out["loss_d"])
+
+
 def gen_senet():
     _stub("fairseq")
     sys.path.insert(0, os.path.join(REF, "models"))
@@ -229,5 +259,6 @@ if __name__ == "__main__":
     gen_rawboost()
     gen_losses_eer()
     gen_aasist()
+    gen_train_steps()
     gen_senet()
     gen_protocol()

@@ -368,3 +368,32 @@ def test_trainer_prefetch_pipeline_equals_sequential_steps():
     assert seq[0] == pip[0]
     (a, b), (c, d) = seq[1], pip[1]             # after one update; further steps of this tiny model amplify the atomics' noise
     assert abs(a - c) <= 0.02 * abs(a) and abs(b - d) <= 0.02 * abs(b), (seq, pip)
+
+
+def test_training_steps_match_reference_loop_golden():
+    """tests/golden/train_steps.npz (three steps of the reference's own loop body on fixed features, dropout off) retraced through
+    the C ABI: back-end forward/backward (exact-f32 MFMA), loss kernels, occ_adam_multi.  Tolerances as in the oracle's test."""
+    from oracle import aasist_ref
+    from oracle.fill import fill_like
+    from occm_amd import ops
+    from occm_amd.models.sslassist import AasistBackend
+    GT = golden("train_steps.npz")
+    be = AasistBackend(fill_like(aasist_ref.param_shapes(), seed=0), device="cuda", compute="f32")
+    opt = ops.AdamMulti([be.P], lr=1e-4)
+    labels = (torch.arange(12) >= 6).long().cuda()
+    for step in range(3):
+        feats = torch.randn(12, 199, 1024, generator=torch.Generator().manual_seed(200 + step)).cuda()
+        be.zero_grad()
+        emb, logits = be.forward(feats, train=True, masks={})
+        lc, demb = ops.compactness_loss(emb, n_groups=1, group=12, scale=0.1, want_grad=True)
+        ld, dlog = ops.ce_loss(logits, labels, scale=0.9, want_grad=True)
+        be.backward(demb, dlog)
+        opt.step([be.G])
+        rt = 2e-4 if step == 0 else 2e-2
+        np.testing.assert_allclose(float(lc), GT["loss_c"][step], rtol=rt)
+        np.testing.assert_allclose(float(ld), GT["loss_d"][step], rtol=rt)
+    sd = be.state_dict()
+    for k in GT.files:
+        if k.startswith("p_") and GT[k].dtype.kind == "f":
+            np.testing.assert_allclose(sd[k[2:]].cpu().numpy().reshape(GT[k].shape), GT[k], rtol=0, atol=6.1e-4)
+    assert int(sd["first_bn.num_batches_tracked"]) == 3

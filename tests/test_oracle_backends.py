@@ -80,3 +80,30 @@ def test_senet(tag, shape, seed):
         com, des = senet_ref.senet34_forward(x, p, train=True)
     np.testing.assert_allclose(com.numpy(), GS["train_com_" + tag], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(des.numpy(), GS["train_des_" + tag], rtol=2e-4, atol=2e-5)
+
+
+def test_oracle_training_steps_match_reference_loop():
+    """tests/golden/train_steps.npz: three steps of the reference's loop body (zero_grad, forward, 0.1 c + 0.9 d, backward, Adam 1e-4)
+    run by models/sslassist.py + losses/custom_loss.py + torch.optim.Adam themselves; the oracle must retrace them."""
+    GT = golden("train_steps.npz")
+    p = fill_like(aasist_ref.param_shapes(), seed=0)
+    q = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in p.items()}
+    opt = torch.optim.Adam([v for v in q.values() if torch.is_tensor(v) and v.requires_grad], lr=1e-4)
+    labels = (torch.arange(12) >= 6).long()
+    for step in range(3):
+        feats = torch.randn(12, 199, 1024, generator=torch.Generator().manual_seed(200 + step))
+        opt.zero_grad()
+        emb, logit = aasist_ref.backend_forward(feats, q, train=True, masks={})
+        lc, ld = losses_ref.compactness_loss(emb), losses_ref.descriptiveness_loss(logit, labels)
+        (0.1 * lc + 0.9 * ld).backward()
+        opt.step()
+        # step 0 is a pure forward of identical parameters.  Adam's first updates are sign-like (g / (|g| + 1e-8)): parameters whose
+        # gradient is rounding noise (biases in front of a train-mode BatchNorm, ...) move by +-lr in an implementation-dependent
+        # direction, so later losses agree to percent level only and a parameter may differ by up to 2*lr per step.
+        rt = 2e-4 if step == 0 else 2e-2
+        np.testing.assert_allclose(float(lc.detach()), GT["loss_c"][step], rtol=rt)
+        np.testing.assert_allclose(float(ld.detach()), GT["loss_d"][step], rtol=rt)
+    for k in GT.files:
+        if k.startswith("p_") and GT[k].dtype.kind == "f":
+            np.testing.assert_allclose(q[k[2:]].detach().numpy(), GT[k], rtol=0, atol=6.1e-4)
+    assert int(q["first_bn.num_batches_tracked"]) == int(GT["p_first_bn.num_batches_tracked"]) == 3
