@@ -10,7 +10,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_st
 cp $ROOT/gpurun_out/prof_stats/bench_kernel_stats.csv $ROOT/gpurun_out/${TAG}_bench_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $ROOT/gpurun_out/prof_fetch -o bench -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-overlap > /dev/null 2> $ROOT/gpurun_out/prof_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $ROOT/gpurun_out/prof_write -o bench -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-overlap > /dev/null 2> $ROOT/gpurun_out/prof_write.err
+rocprofv3 --pmc MfmaUtil GRBM_GUI_ACTIVE --output-format csv -d $ROOT/gpurun_out/prof_mfma -o bench -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-overlap > /dev/null 2> $ROOT/gpurun_out/prof_mfma.err
 cd $ROOT
+python3 scripts/pmc_mfma_summary.py gpurun_out/prof_mfma/bench_counter_collection.csv gpurun_out/${TAG}_pmc_mfma.json
+rm -rf gpurun_out/prof_mfma
 python3 scripts/pmc_summary.py gpurun_out/prof_fetch/bench_counter_collection.csv gpurun_out/prof_write/bench_counter_collection.csv gpurun_out/${TAG}_pmc_hbm.json
 rm -rf gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_stats
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
