@@ -24,6 +24,7 @@ struct TnArgs {
     float* C; long long ldc;
     long long rows_per_split;
     float alpha;
+    int atomic;               // gemm_tn_dma_kernel: several row splits add into C -> atomics; one split: plain read-modify-write
     int t1, t2;               // tiles along N1 / N2 (grid is 1-D: XCD-aware order, see tn_block)
     float* colsum;            // optional: colsum[n1] += alpha * sum_m A[m, n1] (bias gradient), done by the n2-tile-0 workgroups
 };
@@ -249,6 +250,112 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_bf16_kernel(const TnArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Large weight gradients (front-end fine-tuning: C[N1,N2] += dY[M,N1]^T . X[M,N2] with N1, N2 in the thousands): the 128x128
+// LDS-DMA tiling of occ_gemm turned around.  Both operands are bf16 row-major with the reduction index m as the ROW, so they are
+// staged as they lie in memory (64 rows x 256 B per operand and slab, one 1 KiB DMA = 4 rows) and the fragments -- 8 consecutive
+// m per lane -- are read with the transposing ds_read_b64_tr_b16.  No transposed copies of dY / X are ever written, which is
+// what the transpose + occ_gemm formulation spent ~10 % of a fine-tuning step on.
+//   * swizzle: the 32-byte column block cb of row r sits at block cb ^ (r & 7); the 8 consecutive rows a 32-lane half of a
+//     transposing read touches then fall on 8 disjoint bank octets (applied on the DMA's source address, LDS stays lane-linear);
+//   * k-slot (g, h, q) of a 32-row block <-> LDS row 16h + 4g + q on both operands;
+//   * MFMA(a = X fragment, b = dY fragment): a lane ends with C[n1][n2 .. n2+3], i.e. 16-byte accesses to C;
+//   * the bias gradient (column sums of dY) is a separate colsum launch: fusing it (one MFMA per dY fragment against a fragment of
+//     ones) pushed the kernel over 128 VGPRs and cost 15-45 % of its run time.
+typedef __attribute__((address_space(3))) void tn_lds_void;
+typedef __attribute__((address_space(1))) const void tn_gbl_void;
+constexpr int TD = 128, SLD = 64;
+__global__ __launch_bounds__(256, 4) void gemm_tn_dma_kernel(const TnArgs a) {
+    __shared__ uint4 lds[2 * SLD * 16];                   // A slab (64 rows x 16 chunks), then B slab
+    int bx, by, bz; tn_block(a, bx, by, bz);
+    const long long n1_0 = (long long)bx * TD, n2_0 = (long long)by * TD;
+    const long long m_begin = (long long)bz * a.rows_per_split;
+    const long long m_end = m_begin + a.rows_per_split < a.M ? m_begin + a.rows_per_split : a.M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    long long bseg_off = n2_0;
+    if (a.nseg > 1) { const long long sg = n2_0 / a.seg_len; bseg_off = sg * a.seg_stride + (n2_0 - sg * a.seg_len); }
+    // staging: DMA ii = pass * 4 + wave covers rows 4*ii .. 4*ii+3; lane -> (row_local = lane >> 4, 16-byte position p = lane & 15)
+    const int rl = lane >> 4, p16 = lane & 15;
+    // rows 4*ii + rl of this lane have (row & 7) = (4*wave + rl) & 7 for every pass: one swizzled column offset per operand
+    const int cb = (p16 >> 1) ^ ((4 * wave + rl) & 7);
+    long long c1 = n1_0 + cb * 16 + (p16 & 1) * 8; if (c1 > a.N1 - 8) c1 = a.N1 - 8;           // columns past N1 / N2 feed outputs that are never stored
+    long long c2 = cb * 16 + (p16 & 1) * 8; if (n2_0 + c2 > a.N2 - 8) c2 = a.N2 - 8 - n2_0;
+    const unsigned short* Ap = (const unsigned short*)a.A + c1;
+    const unsigned short* Bp = (const unsigned short*)a.B + bseg_off + c2;
+    const bool plain = a.amap.rpl == 0 && a.bmap.rpl == 0 && a.amap.rpb >= a.M && a.bmap.rpb >= a.M;     // plain matrices: offset = m * row_stride
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int fr = lane & 15, g = lane >> 4, q = fr >> 2, pp = lane & 3;
+    unsigned char* ldsA = reinterpret_cast<unsigned char*>(lds);
+    unsigned char* ldsB = ldsA + SLD * 256;
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+    for (long long m0 = m_begin; m0 < m_end; m0 += SLD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ii = i * 4 + wave;
+            long long m = m0 + 4 * ii + rl; if (m > m_end - 1) m = m_end - 1;
+            const long long oa = plain ? m * a.amap.rstride : row_off(a.amap, m), ob = plain ? m * a.bmap.rstride : row_off(a.bmap, m);
+            __builtin_amdgcn_global_load_lds((tn_gbl_void*)(Ap + oa), (tn_lds_void*)&lds[ii * 64], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((tn_gbl_void*)(Bp + ob), (tn_lds_void*)&lds[SLD * 16 + ii * 64], 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (m0 + SLD > m_end) {                             // last, partial slab: rows past the end must not contribute
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ii = i * 4 + wave;
+                if (m0 + 4 * ii + rl >= m_end) { lds[ii * 64 + lane] = make_uint4(0, 0, 0, 0); lds[SLD * 16 + ii * 64 + lane] = make_uint4(0, 0, 0, 0); }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf8 af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s16x4 ar[2], br[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = kb * 32 + 16 * h + 4 * g + q;
+                    ar[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsA + row * 256 + (((wi * 4 + t) ^ (row & 7)) << 5) + pp * 8));
+                    br[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsB + row * 256 + (((wj * 4 + t) ^ (row & 7)) << 5) + pp * 8));
+                }
+                af[t] = __builtin_bit_cast(bf8, __builtin_shufflevector(ar[0], ar[1], 0, 1, 2, 3, 4, 5, 6, 7));
+                bf[t] = __builtin_bit_cast(bf8, __builtin_shufflevector(br[0], br[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) acc[ia][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ib], af[ia], acc[ia][ib], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[row = n2 (4g + r)][col = n1 (fr)]: this lane owns C[n1][n2 .. n2+3]
+#pragma unroll
+    for (int ia = 0; ia < 4; ++ia) {
+        const long long n1 = n1_0 + wi * 64 + ia * 16 + fr;
+        if (n1 >= a.N1) continue;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const long long n2 = n2_0 + wj * 64 + ib * 16 + g * 4;
+            if (n2 >= a.N2) continue;                       // N2 % 4 == 0
+            float* cp = a.C + n1 * a.ldc + n2;
+            if (a.atomic) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(cp + e, acc[ia][ib][e] * a.alpha);
+            } else {
+                f32x4 c = *reinterpret_cast<f32x4*>(cp);
+                c += acc[ia][ib] * a.alpha;
+                *reinterpret_cast<f32x4*>(cp) = c;
+            }
+        }
+    }
+}
+
 // out[n] += alpha * sum_m A[m, n]
 template <typename T>
 __global__ __launch_bounds__(THREADS) void colsum_kernel(const T* __restrict__ A, RowMapI amap, long long M, long long N,
@@ -264,6 +371,44 @@ __global__ __launch_bounds__(THREADS) void colsum_kernel(const T* __restrict__ A
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && n < N) atomicAdd(out + n, (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * alpha);
+}
+
+// bf16 column sums with 16-byte loads: a workgroup owns 64 columns x one row range; thread = (8-column group, row lane)
+__global__ __launch_bounds__(THREADS) void colsum_bf16_vec_kernel(const unsigned short* __restrict__ A, RowMapI amap, long long M, long long N,
+                                                                 long long rows_per_split, float* __restrict__ out, float alpha) {
+    __shared__ float red[32][64];
+    const int cg = threadIdx.x & 7, rlane = threadIdx.x >> 3;
+    const long long c0 = (long long)blockIdx.x * 64 + cg * 8;
+    const long long m_begin = (long long)blockIdx.y * rows_per_split;
+    const long long m_end = m_begin + rows_per_split < M ? m_begin + rows_per_split : M;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c0 < N)                                           // N % 8 == 0
+        for (long long m = m_begin + rlane; m < m_end; m += 32) {
+            const uint4 u = *reinterpret_cast<const uint4*>(A + row_off(amap, m) + c0);
+            const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[2 * e] += __uint_as_float(w[e] << 16); s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rlane][cg * 8 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+        const long long n = (long long)blockIdx.x * 64 + threadIdx.x;
+        if (n < N) atomicAdd(out + n, t * alpha);
+    }
+}
+
+static void launch_colsum_bf16_vec(const unsigned short* A, const RowMapI& amap, long long M, long long N, float* out, float alpha, hipStream_t s) {
+    long long split = occ_cdiv(M, 1024);
+    const long long cap = occ_cdiv(2048, occ_cdiv(N, 64));
+    if (split > cap) split = cap;
+    if (split < 1) split = 1;
+    const long long rps = occ_cdiv(M, split);
+    split = occ_cdiv(M, rps);
+    hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3((unsigned)occ_cdiv(N, 64), (unsigned)split), dim3(THREADS), 0, s, A, amap, M, N, rps, out, alpha);
 }
 
 }  // namespace
@@ -286,7 +431,27 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
     a.M = d->M; a.N1 = d->N1; a.N2 = d->N2;
     a.A = d->A; a.amap = to_rowmap(d->a_map);
     a.B = d->B; a.bmap = to_rowmap(d->b_map); a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->b_seg_stride;
-    a.C = (float*)d->C; a.ldc = d->ldc; a.alpha = d->alpha; a.colsum = (float*)d->colsum;
+    a.C = (float*)d->C; a.ldc = d->ldc; a.alpha = d->alpha; a.colsum = (float*)d->colsum; a.atomic = 1;
+    const bool abf0 = d->a_dtype == OCC_BF16, bbf0 = d->b_dtype == OCC_BF16;
+    static const int dma_env = getenv("OCC_TN_DMA") ? atoi(getenv("OCC_TN_DMA")) : 1;
+    if (dma_env && d->compute == OCC_BF16 && abf0 && bbf0 && d->N1 % 8 == 0 && d->N2 % 8 == 0 && d->N1 >= 128 && d->N2 >= 128 && d->M >= 256 &&
+        (nseg == 1 || seg_len % TD == 0) && d->ldc % 4 == 0 && ((uintptr_t)d->C & 15) == 0 &&
+        d->a_map.row_stride % 8 == 0 && d->a_map.batch_stride % 8 == 0 && d->a_map.line_stride % 8 == 0 &&
+        d->b_map.row_stride % 8 == 0 && d->b_map.batch_stride % 8 == 0 && d->b_map.line_stride % 8 == 0 && (nseg == 1 || d->b_seg_stride % 8 == 0)) {
+        const long long u1 = occ_cdiv(d->N1, TD), u2 = occ_cdiv(d->N2, TD);
+        long long sp = occ_cdiv(512, u1 * u2);                          // ~2 workgroups per CU: the f32 atomics of a split are not free
+        const long long msp = d->M / 256;
+        if (sp > msp) sp = msp;
+        if (sp < 1) sp = 1;
+        a.rows_per_split = occ_cdiv(occ_cdiv(d->M, sp), SLD) * SLD;
+        sp = occ_cdiv(d->M, a.rows_per_split);
+        a.t1 = (int)u1; a.t2 = (int)u2; a.atomic = sp > 1;
+        OCC_CHECK_ARG(u1 * u2 * sp < (1ll << 30), "occ_gemm_tn: output too large");
+        hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3((unsigned)(u1 * u2 * sp)), dim3(THREADS), 0, (hipStream_t)stream, a);
+        if (a.colsum) launch_colsum_bf16_vec((const unsigned short*)a.A, a.amap, a.M, a.N1, a.colsum, a.alpha, (hipStream_t)stream);
+        OCC_LAUNCH_CHECK("occ_gemm_tn");
+        return OCC_OK;
+    }
     const long long t1 = occ_cdiv(d->N1, TT), t2 = occ_cdiv(d->N2, TT);
     static const long long target = getenv("OCC_TN_BLOCKS") ? atoll(getenv("OCC_TN_BLOCKS")) : 1024;
     long long split = occ_cdiv(target, t1 * t2);                     // aim at ~1024 workgroups

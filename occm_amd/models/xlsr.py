@@ -278,7 +278,7 @@ class XlsrFineTuner(XlsrFrontend):
 
     f32 master weights / gradients live in two flat buffers (one Adam tensor, one all-reduce stream); every step the GEMM
     operands are refreshed from them: W as bf16 (forward) and W^T as bf16 (input gradients).  Weight gradients are
-    dW = dY^T.X computed by the same bf16 MFMA GEMM on transposed bf16 copies ([N, Mp] and [K, Mp], Mp = M rounded up to 64).
+    dW = dY^T.X straight from the row-major bf16 dY / X (occ_gemm_tn: LDS-DMA staging, transposing LDS reads, bf16 MFMA).
     Saved for backward per layer: the f32 residual stream before each LayerNorm, the LayerNorm outputs, qkv, the attention
     output and its log-sum-exp, the pre-GELU and post-GELU FFN activations (about 230 MB per layer at B=32)."""
 
@@ -396,9 +396,6 @@ class XlsrFineTuner(XlsrFrontend):
                                      "x_mid": e(M, D, dt=f32), "h2": e(M, D), "u": e(M, Fd), "f": e(M, Fd)})
             tr["x_out"] = e(M, D, dt=f32)
             # transposed operand buffers (pad columns stay zero) and gradient activations
-            tr["tA_D"], tr["tB_D"] = z(D, Mp), z(D, Mp)
-            tr["tA_F"], tr["tB_F"] = z(Fd, Mp), z(Fd, Mp)
-            tr["tA_3D"] = z(3 * D, Mp)
             tr["dx"] = e(M, D, dt=f32)
             tr["dxb"] = e(M, D)                                   # bf16 copy of the residual-stream gradient (GEMM operand)
             tr["du"], tr["dh"], tr["da"], tr["dqkv"] = e(M, Fd), e(M, D), e(M, D), e(M, 3 * D)
@@ -468,12 +465,12 @@ class XlsrFineTuner(XlsrFrontend):
         from .. import backend_ops as K
         K.fill(self.G, 0.0)
 
-    def _wgrad(self, dy, x, N, Kd, M, Mp, tA, tB, gname, bias_name):
-        """G[gname] [N,Kd] += dy^T x ; G[bias] += colsum(dy).  dy [M,N], x [M,Kd] (f32 or bf16)."""
-        ops.transpose_bf16(dy, tA, M, N, ld_src=N, ld_dst=Mp, colsum=self.mg[bias_name])      # bias gradient rides along
-        ops.transpose_bf16(x, tB, M, Kd, ld_src=Kd, ld_dst=Mp)
-        g = self.mg[gname]
-        ops.gemm_raw(N, Kd, Mp, tA, rowmap(N, 0, Mp), tB, Mp, g, rowmap(N, 0, Kd), OCC_F32, OCC_BF16_CODE, R=g, r_map=rowmap(N, 0, Kd), r_dtype=OCC_F32)
+    def _wgrad(self, dy, x, N, Kd, M, gname, bias_name):
+        """G[gname] [N,Kd] += dy^T x ; G[bias] += colsum(dy).  dy [M,N], x [M,Kd], both bf16 as they lie in memory: occ_gemm_tn's
+        LDS-DMA / transposing-read kernel needs no transposed copies."""
+        from .. import backend_ops as K
+        K.gemm_tn(M, N, Kd, dy, rowmap(M, 0, N), x, rowmap(M, 0, Kd), self.mg[gname], Kd, colsum_out=self.mg[bias_name], a_bf16=True, b_bf16=True,
+                  bf16_mfma=True)
 
     def backward(self, dfeats):
         """dfeats f32 [B,T,dim] (gradient wrt the returned features) -> accumulates into self.G."""
@@ -491,16 +488,16 @@ class XlsrFineTuner(XlsrFrontend):
         for i in range(cfg.layers - 1, -1, -1):
             s = tr["layers"][i]
             # ---- FFN: x3 = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-            self._wgrad(dx, s["f"], D, Fd, M, Mp, tr["tA_D"], tr["tB_F"], "l%d.fc2.w" % i, "l%d.fc2.b" % i)
+            self._wgrad(dxb, s["f"], D, Fd, M, "l%d.fc2.w" % i, "l%d.fc2.b" % i)
             ops.gemm_raw(M, Fd, D, dxb, xmap, self.wT["l%d.fc2.w" % i], D, tr["du"], fmap, bfc, bfc, act=ACT_GELU_GRAD, aux=s["u"])
-            self._wgrad(tr["du"], s["h2"], Fd, D, M, Mp, tr["tA_F"], tr["tB_D"], "l%d.fc1.w" % i, "l%d.fc1.b" % i)
+            self._wgrad(tr["du"], s["h2"], Fd, D, M, "l%d.fc1.w" % i, "l%d.fc1.b" % i)
             ops.gemm_raw(M, D, Fd, tr["du"], fmap, self.wT["l%d.fc1.w" % i], Fd, tr["dh"], xmap, bfc, bfc)
             ops.layernorm_bwd(tr["dh"], s["x_mid"], w["l%d.ln2.g" % i], dx, dx, self.mg["l%d.ln2.g" % i], self.mg["l%d.ln2.b" % i], dx_bf16=dxb)
             # ---- attention: x_mid = x_in + out_proj(attn(qkv(LN1(x_in))))
-            self._wgrad(dx, s["att"], D, D, M, Mp, tr["tA_D"], tr["tB_D"], "l%d.o.w" % i, "l%d.o.b" % i)
+            self._wgrad(dxb, s["att"], D, D, M, "l%d.o.w" % i, "l%d.o.b" % i)
             ops.gemm_raw(M, D, D, dxb, xmap, self.wT["l%d.o.w" % i], D, tr["da"], xmap, bfc, bfc)
             ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
-            self._wgrad(tr["dqkv"], s["h1"], 3 * D, D, M, Mp, tr["tA_3D"], tr["tB_D"], "l%d.qkv.w" % i, "l%d.qkv.b" % i)
+            self._wgrad(tr["dqkv"], s["h1"], 3 * D, D, M, "l%d.qkv.w" % i, "l%d.qkv.b" % i)
             ops.gemm_raw(M, D, 3 * D, tr["dqkv"], qmap, self.wT["l%d.qkv.w" % i], 3 * D, tr["dh"], xmap, bfc, bfc)
             ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i], dx_bf16=dxb)
         self.ctx = None
@@ -630,14 +627,10 @@ class XlsrFullFineTuner(XlsrFineTuner):
             z = lambda *s, dt=bf: torch.zeros(*s, device=dev, dtype=dt)
             cv = {"act": [e(B, Ts[i], 512) for i in range(7)], "pre": [None] + [e(B * Ts[i], 512) for i in range(1, 7)],
                   "dact": [z(B, Ts[i], 512) for i in range(7)], "dpre": [None] + [z(B, Ts[i] + 2, 512) for i in range(1, 7)]}
-            # per-layer transposed operands: their pad columns [R, Mp) must stay zero, so the buffers are not shared across layers
-            cv["tA"] = [None] + [z(512, (B * Ts[i] + 63) // 64 * 64) for i in range(1, 7)]
-            cv["tB"] = [None] + [z(CONV_LAYERS[i][1] * 512, (B * Ts[i] + 63) // 64 * 64) for i in range(1, 7)]
             cv["lnfeat"] = e(M, 512)
             cv["u_pos"] = e(M, D)
             cv["dupad"] = z(B, T + cfg.pos_k, D)
             cv["dln"] = e(M, 512)
-            cv["tA_proj"], cv["tB_proj"] = z(D, tr["Mp"]), z(512, tr["Mp"])
             tr["conv"] = cv
         return ws
 
@@ -696,10 +689,8 @@ class XlsrFullFineTuner(XlsrFineTuner):
         ops.gemm_raw(M, cg, Kp * cg, dupad, dmap, self.wT["pos.w"], Kp * cg, dx, xm, OCC_F32, bfc, R=dx, r_map=xm, r_dtype=OCC_F32,
                      a_seg=(Kp, cg, D), groups=(G, cg, cg * Kp * cg, cg))
         # ---- post_extract_proj + LayerNorm(512) --------------------------------------------------------------------
-        ops.transpose_bf16(dx, cv["tA_proj"], M, D, ld_src=D, ld_dst=Mp, colsum=self.mg["proj.b"])
-        ops.transpose_bf16(cv["lnfeat"], cv["tB_proj"], M, 512, ld_src=512, ld_dst=Mp)
-        gw = self.mg["proj.w"]
-        ops.gemm_raw(D, 512, Mp, cv["tA_proj"], rowmap(D, 0, Mp), cv["tB_proj"], Mp, gw, rowmap(D, 0, 512), OCC_F32, bfc, R=gw, r_map=rowmap(D, 0, 512), r_dtype=OCC_F32)
+        check(lib().occ_cast(ptr(dx), OCC_F32, ptr(tr["dxb"]), bfc, M * D, stream_ptr()), "occ_cast")      # dx changed since its bf16 copy was made
+        self._wgrad(tr["dxb"], cv["lnfeat"], D, 512, M, "proj.w", "proj.b")
         ops.gemm_raw(M, 512, D, dx, xm, self.wT["proj.w"], D, cv["dln"], rowmap(M, 0, 512), bfc, OCC_AF32_WBF16)
         ops.layernorm_bwd_ex(cv["dln"], cv["act"][6].view(M, 512), w["ln.g"], None, None, None, cv["dact"][6].view(M, 512), None, self.mg["ln.g"], self.mg["ln.b"], gelu=False)
         # ---- conv blocks 6..1 ------------------------------------------------------------------------------------------
@@ -714,14 +705,10 @@ class XlsrFullFineTuner(XlsrFineTuner):
             ops.layernorm_bwd_ex(cv["dact"][i].view(R, 512), cv["pre"][i], w["c%d.g" % i], w["c%d.be" % i], None, None, d_in, imap,
                                  self.mg["c%d.g" % i], self.mg["c%d.be" % i], gelu=True)
             # weight gradient: dW[n][(tap,c)] = sum_m dpre[m][n] * act_{i-1}[b, s*t + tap, c]
-            tA, tB = cv["tA"][i], cv["tB"][i]
-            ldT = tA.shape[1]
-            ops.transpose_bf16_rows(d_in, imap, tA, R, 512, ld_dst=ldT, colsum=self.mg["c%d.b" % i], src_dtype=bfc)
-            for tap in range(k):
-                ops.transpose_bf16_rows(cv["act"][i - 1].data_ptr() + tap * 512 * 2, rowmap(Tout, Tin * 512, s * 512), tB.data_ptr() + tap * 512 * ldT * 2, R, 512,
-                                        ld_dst=ldT, src_dtype=bfc)
-            gwi = self.mg["c%d.w" % i].view(512, k * 512)
-            ops.gemm_raw(512, k * 512, Mpi, tA, rowmap(512, 0, ldT), tB, ldT, gwi, rowmap(512, 0, k * 512), OCC_F32, bfc, R=gwi, r_map=rowmap(512, 0, k * 512), r_dtype=OCC_F32)
+            # (the k taps of a window are contiguous in the channels-last activation: the window IS the B row, row stride s*512)
+            from .. import backend_ops as K
+            K.gemm_tn(R, 512, k * 512, d_in, imap, cv["act"][i - 1], rowmap(Tout, Tin * 512, s * 512), self.mg["c%d.w" % i].view(512, k * 512), k * 512,
+                      colsum_out=self.mg["c%d.b" % i], a_bf16=True, b_bf16=True, bf16_mfma=True)
             # input gradient
             dprev = cv["dact"][i - 1]
             if k == 3:

@@ -17,3 +17,21 @@ for N, Kd, M in shapes:
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 10)
     us = sorted(ts)[2] * 1e3
     print("N=%5d Kd=%5d M=%7d  %8.1f us  %6.0f TFLOP/s" % (N, Kd, M, us, 2 * N * Kd * M / us / 1e6), flush=True)
+
+# the same products with the operands as they lie in memory ([M, N] row-major): LDS-DMA + transposing-read kernel, no transposes
+from occm_amd import backend_ops as K
+for with_cs in (True, False):
+  print("occ_gemm_tn (bf16 operands, no transposed copies)%s:" % (", fused bias gradient" if with_cs else ""))
+  for N, Kd, M in shapes:
+      a = torch.randn(M, N, device="cuda").bfloat16(); b = torch.randn(M, Kd, device="cuda").bfloat16()
+      C = torch.zeros(N, Kd, device="cuda"); cs = torch.zeros(N, device="cuda") if with_cs else None
+      f = lambda: K.gemm_tn(M, N, Kd, a, K.full(M, N), b, K.full(M, Kd), C, Kd, colsum_out=cs, a_bf16=True, b_bf16=True, bf16_mfma=True)
+      for _ in range(3): f()
+      ts = []
+      for r in range(5):
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          e0.record()
+          for _ in range(10): f()
+          e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 10)
+      us = sorted(ts)[2] * 1e3
+      print("N=%5d Kd=%5d M=%7d  %8.1f us  %6.0f TFLOP/s" % (N, Kd, M, us, 2 * N * Kd * M / us / 1e6), flush=True)

@@ -397,3 +397,34 @@ def test_training_steps_match_reference_loop_golden():
         if k.startswith("p_") and GT[k].dtype.kind == "f":
             np.testing.assert_allclose(sd[k[2:]].cpu().numpy().reshape(GT[k].shape), GT[k], rtol=0, atol=6.1e-4)
     assert int(sd["first_bn.num_batches_tracked"]) == 3
+
+
+@pytest.mark.parametrize("M,N1,N2", [(12736, 1024, 1024), (4099, 256, 384), (300, 128, 136), (25536, 512, 1024)])
+def test_gemm_tn_dma_large_weight_gradients(M, N1, N2):
+    """bf16 operands, bf16 MFMA, big outputs: the LDS-DMA / transposing-read kernel (no transposed copies), incl. a ragged last slab,
+    ragged column tiles and the fused bias gradient; accumulates onto what C holds."""
+    from occm_amd import backend_ops as K
+    a = _r(M, N1, seed=1).bfloat16(); b = _r(M, N2, seed=2).bfloat16()
+    c0 = _r(N1, N2, seed=3)
+    C, s = c0.clone().cuda(), torch.zeros(N1).cuda()
+    K.gemm_tn(M, N1, N2, a.cuda(), K.full(M, N1), b.cuda(), K.full(M, N2), C, N2, colsum_out=s, a_bf16=True, b_bf16=True, bf16_mfma=True)
+    ref = c0.double() + a.double().T @ b.double()
+    torch.testing.assert_close(C.cpu().double(), ref, rtol=1e-4, atol=2e-6 * float(ref.abs().max()) + 2e-4)
+    torch.testing.assert_close(s.cpu().double(), a.double().sum(0), rtol=1e-4, atol=2e-3)
+
+
+def test_gemm_tn_dma_conv_windows():
+    """B rows are k=3, stride-2 windows of a channels-last [B, Tin, 512] signal (three K-segments of 512), A rows the conv output
+    gradient: the conv-stack weight gradient of the fine-tuning path without materialising the windows."""
+    from occm_amd import backend_ops as K
+    Bn, Tin, Cc, k, st = 3, 401, 512, 3, 2
+    Tout = (Tin - k) // st + 1
+    M = Bn * Tout
+    x = _r(Bn, Tin, Cc, seed=5).bfloat16()
+    dy = _r(M, Cc, seed=6).bfloat16()
+    win = torch.stack([x[:, t * st: t * st + k].reshape(Bn, k * Cc) for t in range(Tout)], 1).reshape(M, k * Cc)
+    C = torch.zeros(Cc, k * Cc).cuda()
+    K.gemm_tn(M, Cc, k * Cc, dy.cuda(), K.full(M, Cc), x.cuda(), K.rowmap(Tout, Tin * Cc, st * Cc), C, k * Cc, b_seg=(k, Cc, Cc), a_bf16=True, b_bf16=True,
+              bf16_mfma=True)
+    ref = dy.double().T @ win.double()
+    torch.testing.assert_close(C.cpu().double(), ref, rtol=1e-4, atol=2e-6 * float(ref.abs().max()) + 2e-4)
