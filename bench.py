@@ -128,6 +128,8 @@ def main():
                     "minus RawBoost; encoder = transformer only); prints the same JSON with a different workload name")
     ap.add_argument("--bs", type=int, default=BS, help="per-GPU batch (headline: 32)")
     ap.add_argument("--rawboost", type=int, default=0, help="RawBoost algo 1-8 applied on the GPU inside the timed step (configs[2]: 5)")
+    ap.add_argument("--backend", default="aasist", choices=["aasist", "senet"], help="NOT the headline config with senet: SE-ResNet34 on the XLS-R "
+                    "features (models/senet.py ssl_resnet34, loss 0.1 c + 0.9 d as test_dataloader_v2.py:127)")
     ap.add_argument("--no-overlap", action="store_true", help="do not compute the next batch's frozen-front-end features on a side stream "
                     "while the back-end trains on the current one")
     ap.add_argument("--split", type=int, default=1, help="run the front-end as this many concurrent sub-batches on separate HIP "
@@ -146,9 +148,15 @@ def main():
     dev = torch.device("cuda", local)
     cfg = xlsr.XlsrConfig.xlsr_300m()
     bs = args.bs
-    model = AModel(None, dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, seed=0, finetune_ssl=args.finetune or False)
+    if args.backend == "senet":
+        from occm_amd.models.senet import ssl_resnet34
+        model = ssl_resnet34(dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, finetune_ssl=args.finetune or False)
+        wc, wd = 0.1, 0.9
+    else:
+        model = AModel(None, dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, seed=0, finetune_ssl=args.finetune or False)
+        wc, wd = 0.0, 1.0
     model.train()
-    trainer = OcTrainer(model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=bool(args.finetune), rawboost_algo=args.rawboost)
+    trainer = OcTrainer(model, lr=1e-5, w_compact=wc, w_descr=wd, train_frontend=bool(args.finetune), rawboost_algo=args.rawboost, group_size=12 if bs % 12 == 0 else None)
     wav, labels = synth_batch(bs, rank, dev)
     fe = model.ssl_model.model
     if args.finetune:
@@ -232,15 +240,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
-        wl = ("XLSR-300M frozen frontend + AASIST backend, bs=%d per GPU, 64000-sample utterances (BASELINE configs[1])" % bs) if not args.finetune else \
+        if args.backend == "senet":
+            wl = "XLSR-300M %s frontend + SE-ResNet34 backend, bs=%d per GPU (not a BASELINE config; models/senet.py ssl_resnet34)" % ("fine-tuned" if args.finetune else "frozen", bs)
+        else:
+            wl = ("XLSR-300M frozen frontend + AASIST backend, bs=%d per GPU, 64000-sample utterances (BASELINE configs[1])" % bs) if not args.finetune else \
             ("XLSR-300M fine-tuned (%s) + AASIST backend, bs=%d per GPU (BASELINE configs[2]%s)" % (args.finetune, bs, ", RawBoost algo %d on-GPU" % args.rawboost if args.rawboost else " without RawBoost"))
         out = {"metric": "utterances/sec (4 s @16 kHz) training step", "value": round(bs * world * args.steps / dt, 2), "unit": "utterances/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": wl,
                           "global_batch": bs * world, "samples_per_utt": L_SAMPLES, "parallelism": "dp%d" % world,
-                          "frontend": "bf16 MFMA, f32 accumulate, HIP-graph replay" + (", features of step i+1 computed on a side stream during step i's back-end" if overlap else ""), "backend": "fwd+bwd, f32 storage, bf16-MFMA GEMMs (f32 accumulate), f32 wgrad, dropout on, Adam lr=1e-5",
-                          "loss": "0.0*compactness + 1.0*descriptiveness (oc_training.py:380-381)", "final_loss_d": round(loss_d, 5)},
+                          "frontend": "bf16 MFMA, f32 accumulate, HIP-graph replay" + (", features of step i+1 computed on a side stream during step i's back-end" if overlap else ""), "backend": ("fwd+bwd, f32 storage, bf16-MFMA GEMMs and weight gradients (f32 accumulate), dropout on, Adam lr=1e-5" if args.backend == "aasist"
+                                      else "SE-ResNet34 fwd+bwd, f32 storage, exact-f32 MFMA GEMMs, Adam lr=1e-5"),
+                          "loss": "%.1f*compactness + %.1f*descriptiveness (%s)" % (wc, wd, "oc_training.py:380-381" if args.backend == "aasist" else "test_dataloader_v2.py:127"), "final_loss_d": round(loss_d, 5)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:

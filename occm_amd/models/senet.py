@@ -14,7 +14,7 @@ import torch
 
 from .. import backend_ops as K
 from .. import ops
-from .._lib import ACT_NONE, ACT_RELU, OCC_F32, OccError, check, lib, ptr, require_gpu, stream_ptr
+from .._lib import ACT_NONE, ACT_RELU, OCC_F32, OCC_F32_AS_BF16, OccError, check, lib, ptr, require_gpu, stream_ptr
 from ..ops import rowmap
 
 LAYERS = [3, 4, 6, 3]                       # senet.py:154-156
@@ -64,8 +64,13 @@ def _cp(c):
 
 
 class SeResNet34Backend:
-    def __init__(self, params=None, device="cuda", seed=1):
+    def __init__(self, params=None, device="cuda", seed=1, compute="f32"):
+        """compute: "f32" (exact-f32 MFMA, the parity path) or "bf16" (operands rounded to bf16 on the way into LDS, bf16 MFMA, f32
+        accumulate; weight gradients likewise) -- activations, parameters and gradients stay f32 in memory either way."""
         require_gpu()
+        if compute not in ("f32", "bf16"):
+            raise OccError("compute must be 'f32' or 'bf16'")
+        self.compute = compute
         self.device = torch.device(device)
         self.table = senet_param_table()
         self.slots, off = {}, 0
@@ -136,6 +141,17 @@ class SeResNet34Backend:
         K.fill(self.G, 0.0)
 
     # --------------------------------------------------------------------------------------- helpers --
+    def _gemm(self, M, N, Kd, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, a_seg=None, **kw):
+        """occ_gemm; in bf16 compute mode the f32 operands are rounded to bf16 on their way into LDS (bf16 MFMA, f32 accumulate)
+        wherever K and the operand strides are multiples of 8 elements -- everything but the 4-channel stem convolution."""
+        if self.compute == "bf16" and ab_dtype == OCC_F32 and Kd % 8 == 0 and ldw % 8 == 0 and a_map.row_stride % 8 == 0 and \
+                a_map.batch_stride % 8 == 0 and a_map.line_stride % 8 == 0 and (a_seg is None or (a_seg[1] % 8 == 0 and a_seg[2] % 8 == 0)):
+            ab_dtype = OCC_F32_AS_BF16
+        return ops.gemm_raw(M, N, Kd, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, a_seg=a_seg, **kw)
+
+    def _tn(self, *a, **kw):
+        return K.gemm_tn(*a, bf16_mfma=(self.compute == "bf16"), **kw)
+
     def _e(self, *s, dtype=torch.float32):
         return torch.empty(*s, device=self.device, dtype=dtype)
 
@@ -198,7 +214,7 @@ class SeResNet34Backend:
         H1, W1 = geo["c1hw"]
         R0 = B * H1 * W1
         c1 = self._e(R0, 16)
-        ops.gemm_raw(R0, 16, 7 * 7 * 4, X0, rowmap(H1 * W1, (H0 + 6) * Wp0 * 4, 2 * 4, W1, 2 * Wp0 * 4), p["conv1.weight"], 196, c1, rowmap(R0, 0, 16),
+        self._gemm(R0, 16, 7 * 7 * 4, X0, rowmap(H1 * W1, (H0 + 6) * Wp0 * 4, 2 * 4, W1, 2 * Wp0 * 4), p["conv1.weight"], 196, c1, rowmap(R0, 0, 16),
                      OCC_F32, OCC_F32, a_seg=(7, 28, Wp0 * 4))
         c["c1"] = c1
         a1 = self._e(R0, 16)
@@ -219,12 +235,12 @@ class SeResNet34Backend:
             R = B * Ho * Wo
             X, Y = bg["X"], bg["Y"]
             o1 = self._e(R, pl)
-            ops.gemm_raw(R, pl, 9 * inp, X, rowmap(Ho * Wo, (H + 2) * Wp * inp, s * inp, Wo, s * Wp * inp), p[pre + ".conv1.weight"], 9 * inp, o1, rowmap(R, 0, pl),
+            self._gemm(R, pl, 9 * inp, X, rowmap(Ho * Wo, (H + 2) * Wp * inp, s * inp, Wo, s * Wp * inp), p[pre + ".conv1.weight"], 9 * inp, o1, rowmap(R, 0, pl),
                          OCC_F32, OCC_F32, a_seg=(3, 3 * inp, Wp * inp))
             y_in = rowmap(Ho * Wo, (Ho + 2) * Wop * pl, pl, Wo, Wop * pl)
             self._bn_fwd(pre + ".bn1", o1, R, pl, ACT_RELU, Y.data_ptr() + (Wop + 1) * pl * es, y_in, train, c)
             o2 = self._e(R, pl)
-            ops.gemm_raw(R, pl, 9 * pl, Y, rowmap(Ho * Wo, (Ho + 2) * Wop * pl, pl, Wo, Wop * pl), p[pre + ".conv2.weight"], 9 * pl, o2, rowmap(R, 0, pl), OCC_F32, OCC_F32,
+            self._gemm(R, pl, 9 * pl, Y, rowmap(Ho * Wo, (Ho + 2) * Wop * pl, pl, Wo, Wop * pl), p[pre + ".conv2.weight"], 9 * pl, o2, rowmap(R, 0, pl), OCC_F32, OCC_F32,
                          a_seg=(3, 3 * pl, Wop * pl))
             y2 = self._e(R, pl)
             self._bn_fwd(pre + ".bn2", o2, R, pl, ACT_NONE, y2, rowmap(R, 0, pl), train, c)
@@ -235,7 +251,7 @@ class SeResNet34Backend:
             x_in = rowmap(H * W, (H + 2) * Wp * inp, inp, W, Wp * inp)
             if bg["ds"]:
                 dso = self._e(R, pl)
-                ops.gemm_raw(R, pl, inp, X.data_ptr() + (Wp + 1) * inp * es, rowmap(Ho * Wo, (H + 2) * Wp * inp, s * inp, Wo, s * Wp * inp),
+                self._gemm(R, pl, inp, X.data_ptr() + (Wp + 1) * inp * es, rowmap(Ho * Wo, (H + 2) * Wp * inp, s * inp, Wo, s * Wp * inp),
                              p[pre + ".downsample.0.weight"], inp, dso, rowmap(R, 0, pl), OCC_F32, OCC_F32)
                 res = self._e(R, pl)
                 self._bn_fwd(pre + ".downsample.1", dso, R, pl, ACT_NONE, res, rowmap(R, 0, pl), train, c)
@@ -258,9 +274,9 @@ class SeResNet34Backend:
         feat = self._e(B, 128)
         check(lib().occ_batch_colsum(ptr(final), _rm(rowmap(B * Hf * Wf, 0, 128)), B, Hf * Wf, 128, 1.0 / (Hf * Wf), ptr(feat), stream_ptr()), "occ_batch_colsum")
         com, des = self._e(B, 128), self._e(B, 4)
-        ops.gemm_raw(B, 128, 128, feat, rowmap(B, 0, 128), p["embedding.weight"], 128, com, rowmap(B, 0, 128), OCC_F32, OCC_F32, bias=p["embedding.bias"])
+        self._gemm(B, 128, 128, feat, rowmap(B, 0, 128), p["embedding.weight"], 128, com, rowmap(B, 0, 128), OCC_F32, OCC_F32, bias=p["embedding.bias"])
         self._cls_w = self._cls_pad()
-        ops.gemm_raw(B, 4, 128, feat, rowmap(B, 0, 128), self._cls_w[0], 128, des, rowmap(B, 0, 4), OCC_F32, OCC_F32, bias=self._cls_w[1])
+        self._gemm(B, 4, 128, feat, rowmap(B, 0, 128), self._cls_w[0], 128, des, rowmap(B, 0, 4), OCC_F32, OCC_F32, bias=self._cls_w[1])
         c["feat"], c["final"] = feat, final
         self.ctx = c if train else None
         return com, des[:, :2].contiguous()
@@ -289,8 +305,8 @@ class SeResNet34Backend:
         # ---- heads ---------------------------------------------------------------------------------------------------
         dd4 = self._z(B, 4); dd4[:, :2].copy_(ddes)
         gw4, gb4 = self._z(4, 128), self._z(4)
-        K.gemm_tn(B, 128, 128, dcom.contiguous(), rowmap(B, 0, 128), feat, rowmap(B, 0, 128), g["embedding.weight"], 128, colsum_out=g["embedding.bias"])
-        K.gemm_tn(B, 4, 128, dd4, rowmap(B, 0, 4), feat, rowmap(B, 0, 128), gw4, 128, colsum_out=gb4)
+        self._tn(B, 128, 128, dcom.contiguous(), rowmap(B, 0, 128), feat, rowmap(B, 0, 128), g["embedding.weight"], 128, colsum_out=g["embedding.bias"])
+        self._tn(B, 4, 128, dd4, rowmap(B, 0, 4), feat, rowmap(B, 0, 128), gw4, 128, colsum_out=gb4)
         K.axpby(gw4[:2].contiguous().view(-1), g["classifier.weight"].view(-1), g["classifier.weight"].view(-1))
         K.axpby(gb4[:2].contiguous(), g["classifier.bias"], g["classifier.bias"])
         wte = self._e(128, 128)
@@ -298,8 +314,8 @@ class SeResNet34Backend:
         wtc = self._e(128, 4)
         K.copy_strided(self._cls_w[0], wtc, 0, (1, 1, 128, 4), (0, 0, 1, 128))
         dfeat = self._e(B, 128)
-        ops.gemm_raw(B, 128, 128, dcom.contiguous(), rowmap(B, 0, 128), wte, 128, dfeat, rowmap(B, 0, 128), OCC_F32, OCC_F32)
-        ops.gemm_raw(B, 128, 4, dd4, rowmap(B, 0, 4), wtc, 4, dfeat, rowmap(B, 0, 128), OCC_F32, OCC_F32, R=dfeat, r_map=rowmap(B, 0, 128), r_dtype=OCC_F32)
+        self._gemm(B, 128, 128, dcom.contiguous(), rowmap(B, 0, 128), wte, 128, dfeat, rowmap(B, 0, 128), OCC_F32, OCC_F32)
+        self._gemm(B, 128, 4, dd4, rowmap(B, 0, 4), wtc, 4, dfeat, rowmap(B, 0, 128), OCC_F32, OCC_F32, R=dfeat, r_map=rowmap(B, 0, 128), r_dtype=OCC_F32)
         # grad wrt the last block's output: dfeat / (Hf*Wf) broadcast over the positions
         Rf = B * Hf * Wf
         dout = self._z(Rf, 128)
@@ -333,23 +349,23 @@ class SeResNet34Backend:
             d2_in = D2.data_ptr() + (Wop + 1) * pl * es
             y_in = rowmap(Ho * Wo, (Ho + 2) * Wop * pl, pl, Wo, Wop * pl)
             self._bn_bwd(pre + ".bn2", dy2, rowmap(R, 0, pl), sv["o2"], R, pl, ACT_NONE, d2_in, y_in, c)
-            K.gemm_tn(R, pl, 9 * pl, d2_in, y_in, Y, rowmap(Ho * Wo, (Ho + 2) * Wop * pl, pl, Wo, Wop * pl), g[pre + ".conv2.weight"], 9 * pl, b_seg=(3, 3 * pl, Wop * pl))
+            self._tn(R, pl, 9 * pl, d2_in, y_in, Y, rowmap(Ho * Wo, (Ho + 2) * Wop * pl, pl, Wo, Wop * pl), g[pre + ".conv2.weight"], 9 * pl, b_seg=(3, 3 * pl, Wop * pl))
             wd2 = self._flip3(p[pre + ".conv2.weight"], pl, pl)
             dY = self._e(R, pl)
-            ops.gemm_raw(R, pl, 9 * pl, D2, rowmap(Ho * Wo, (Ho + 2) * Wop * pl, pl, Wo, Wop * pl), wd2, 9 * pl, dY, rowmap(R, 0, pl), OCC_F32, OCC_F32, a_seg=(3, 3 * pl, Wop * pl))
+            self._gemm(R, pl, 9 * pl, D2, rowmap(Ho * Wo, (Ho + 2) * Wop * pl, pl, Wo, Wop * pl), wd2, 9 * pl, dY, rowmap(R, 0, pl), OCC_F32, OCC_F32, a_seg=(3, 3 * pl, Wop * pl))
             # bn1 + relu -> grad wrt conv1 output, into D1
             if s == 1:
                 d1_in, d1_map = D1.data_ptr() + (Wop + 1) * pl * es, y_in
             else:
                 d1_in, d1_map = D1.data_ptr(), rowmap(Ho * Wo, (Ho + 1) * (Wo + 1) * pl, pl, Wo, (Wo + 1) * pl)
             self._bn_bwd(pre + ".bn1", dY, rowmap(R, 0, pl), sv["o1"], R, pl, ACT_RELU, d1_in, d1_map, c)
-            K.gemm_tn(R, pl, 9 * inp, d1_in, d1_map, X, rowmap(Ho * Wo, (H + 2) * Wp * inp, s * inp, Wo, s * Wp * inp), g[pre + ".conv1.weight"], 9 * inp,
+            self._tn(R, pl, 9 * inp, d1_in, d1_map, X, rowmap(Ho * Wo, (H + 2) * Wp * inp, s * inp, Wo, s * Wp * inp), g[pre + ".conv1.weight"], 9 * inp,
                       b_seg=(3, 3 * inp, Wp * inp))
             w1 = p[pre + ".conv1.weight"]                       # [pl,3,3,inp]
             full = rowmap(B * H * W, 0, inp)
             if s == 1:
                 wd1 = self._flip3(w1, inp, pl)
-                ops.gemm_raw(B * H * W, inp, 9 * pl, D1, rowmap(H * W, (Ho + 2) * Wop * pl, pl, W, Wop * pl), wd1, 9 * pl, dX, full, OCC_F32, OCC_F32,
+                self._gemm(B * H * W, inp, 9 * pl, D1, rowmap(H * W, (Ho + 2) * Wop * pl, pl, W, Wop * pl), wd1, 9 * pl, dX, full, OCC_F32, OCC_F32,
                              a_seg=(3, 3 * pl, Wop * pl), R=None if bg["ds"] else dX, r_map=None if bg["ds"] else full, r_dtype=OCC_F32)
             else:
                 self._dgrad_s2(bg, B, w1, D1, dX)
@@ -359,11 +375,11 @@ class SeResNet34Backend:
                 ddso = self._e(R, pl)
                 self._bn_bwd(pre + ".downsample.1", dres, rowmap(R, 0, pl), dso, R, pl, ACT_NONE, ddso, rowmap(R, 0, pl), c)
                 xs_map = rowmap(Ho * Wo, (H + 2) * Wp * inp, s * inp, Wo, s * Wp * inp)
-                K.gemm_tn(R, pl, inp, ddso, rowmap(R, 0, pl), X.data_ptr() + (Wp + 1) * inp * es, xs_map, g[pre + ".downsample.0.weight"], inp)
+                self._tn(R, pl, inp, ddso, rowmap(R, 0, pl), X.data_ptr() + (Wp + 1) * inp * es, xs_map, g[pre + ".downsample.0.weight"], inp)
                 wdt = self._e(inp, pl)
                 K.copy_strided(p[pre + ".downsample.0.weight"], wdt, 0, (1, 1, inp, pl), (0, 0, 1, inp))
                 cmap = rowmap(Ho * Wo, H * W * inp, s * inp, Wo, s * W * inp)
-                ops.gemm_raw(R, inp, pl, ddso, rowmap(R, 0, pl), wdt, pl, dX, cmap, OCC_F32, OCC_F32, R=dX, r_map=cmap, r_dtype=OCC_F32)
+                self._gemm(R, inp, pl, ddso, rowmap(R, 0, pl), wdt, pl, dX, cmap, OCC_F32, OCC_F32, R=dX, r_map=cmap, r_dtype=OCC_F32)
             dout_addr, dout_map = dX, full
         # ---- stem: max-pool, bn1+relu, 7x7 conv weight gradient ---------------------------------------------------------------
         H1, W1 = geo["c1hw"]
@@ -376,7 +392,7 @@ class SeResNet34Backend:
         self._bn_bwd("bn1", da1, rowmap(R0, 0, 16), c["c1"], R0, 16, ACT_RELU, dc1, rowmap(R0, 0, 16), c)
         H0, W0 = geo["H0"], geo["W0"]
         Wp0 = W0 + 6
-        K.gemm_tn(R0, 16, 196, dc1, rowmap(R0, 0, 16), geo["X0"], rowmap(H1 * W1, (H0 + 6) * Wp0 * 4, 8, W1, 2 * Wp0 * 4), g["conv1.weight"], 196, b_seg=(7, 28, Wp0 * 4))
+        self._tn(R0, 16, 196, dc1, rowmap(R0, 0, 16), geo["X0"], rowmap(H1 * W1, (H0 + 6) * Wp0 * 4, 8, W1, 2 * Wp0 * 4), g["conv1.weight"], 196, b_seg=(7, 28, Wp0 * 4))
         self.ctx = None
         if want_dfeats:
             dx = self._e(B, H0, W0)
@@ -414,7 +430,7 @@ class SeResNet34Backend:
             if kind is not None and kind[0] in ("rows", "both"):
                 seg = (2, Kd // 2, ld)
             c_map = rowmap(Hc * Wc, H * W * inp, 2 * inp, Wc, 2 * W * inp)
-            ops.gemm_raw(B * Hc * Wc, inp, Kd, D1, a_map, wop, Kd, dX.data_ptr() + (eh * W + ew) * inp * es, c_map, OCC_F32, OCC_F32, a_seg=seg)
+            self._gemm(B * Hc * Wc, inp, Kd, D1, a_map, wop, Kd, dX.data_ptr() + (eh * W + ew) * inp * es, c_map, OCC_F32, OCC_F32, a_seg=seg)
 
 
 def _copy_tap(src, dst, src_off, n_rows, n_cols, src_col_stride, dst_col_off, dst_ld):
@@ -448,9 +464,9 @@ def synthetic_senet_params(seed=1):
 class _SeResNet(torch.nn.Module):
     """Module facade with the reference's call signature (senet.py:120-142)."""
 
-    def __init__(self, state_dict=None, device="cuda", seed=1, **kwargs):
+    def __init__(self, state_dict=None, device="cuda", seed=1, compute="f32", **kwargs):
         super().__init__()
-        self.backend = SeResNet34Backend(state_dict, device=device, seed=seed)
+        self.backend = SeResNet34Backend(state_dict, device=device, seed=seed, compute=compute)
 
     def forward(self, x, eval=False):
         return self.backend.forward(x, train=self.training)
@@ -480,11 +496,14 @@ def se_resnet34(**kwargs):
 class ssl_resnet34(torch.nn.Module):
     """senet.py:162-185: XLS-R features [B,T,1024] -> unsqueeze(1) -> SE-ResNet34."""
 
-    def __init__(self, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, state_dict=None, finetune_ssl=False, seed=1):
+    def __init__(self, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, state_dict=None, finetune_ssl=False, seed=1,
+                 backend_compute=None):
         super().__init__()
         from .xlsr import SSLModel
         self.frontend = SSLModel(device, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, finetune=finetune_ssl)
-        self.resnet34 = se_resnet34(state_dict=state_dict, device=device, seed=seed)
+        if backend_compute is None:         # same rule as AModel: a bf16 front-end brings the bf16-MFMA back-end mode
+            backend_compute = "bf16" if ssl_dtype == torch.bfloat16 else "f32"
+        self.resnet34 = se_resnet34(state_dict=state_dict, device=device, seed=seed, compute=backend_compute)
         # the names OcTrainer drives (shared with AModel)
         self.ssl_model = self.frontend
         self.backend = self.resnet34.backend

@@ -213,3 +213,27 @@ def test_ssl_resnet34_trainer_learns(finetune):
     model.eval()
     com, des = model(wav)
     assert com.shape == (12, 128) and des.shape == (12, 2)
+
+
+def test_senet_bf16_compute_mode_tracks_f32():
+    """compute="bf16" (operands rounded to bf16 on the way into LDS, bf16 MFMA, f32 accumulate; f32 storage): outputs within bf16
+    accuracy of the exact-f32 path; the full gradient keeps a cosine >= 0.9 (the same bar as the AASIST bf16 mode: train-mode BatchNorm
+    over a small batch plus 33 ReLU / max-pool layers make single gradients jumpy under operand rounding; measured 0.943)."""
+    from occm_amd.models.senet import se_resnet34
+    p = _params()
+    x = _x((4, 1, 120, 256), 21).cuda()
+    dcom = torch.randn(4, 128, generator=torch.Generator().manual_seed(22)).cuda()
+    ddes = torch.randn(4, 2, generator=torch.Generator().manual_seed(23)).cuda()
+    outs, grads = {}, {}
+    for mode in ("f32", "bf16"):
+        net = se_resnet34(state_dict=p, compute=mode)
+        net.train()
+        com, des = net(x)
+        net.backend.zero_grad()
+        net.backward(dcom, ddes)
+        outs[mode] = (com.clone(), des.clone())
+        grads[mode] = net.backend.G.clone()
+    for a, b in zip(outs["f32"], outs["bf16"]):
+        assert float((a - b).abs().max()) <= 3e-2 * max(1.0, float(a.abs().max()))
+    cos = float(torch.dot(grads["f32"], grads["bf16"]) / (grads["f32"].norm() * grads["bf16"].norm()))
+    assert cos >= 0.9, cos
