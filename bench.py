@@ -228,11 +228,12 @@ def main():
         traffic, tnote = None, None
         try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
-            traffic = pm["kernels"]["gemm_bf16_dma_kernel<128>"]["hbm_bytes_per_launch_corrected"]
+            ks = [v for k, v in pm["kernels"].items() if k.startswith("gemm_bf16_")]          # the bf16 GEMM family (default + half-slab kernels)
+            traffic = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks))
             tnote = "profiles/r01_pmc_hbm.json (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE)"
         except (OSError, KeyError, ValueError):
             pass
-        roof = {"kernel": "gemm_bf16_dma_kernel (all front-end Linear/Conv1d launches of one step)", "bound": "mfma",
+        roof = {"kernel": "bf16 GEMM (gemm_bf16_dma_kernel, gemm_bf16_hs_kernel: all front-end Linear/Conv1d launches of one step)", "bound": "mfma",
                 "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": tnote, "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(cfg, L_SAMPLES, bs) / max(n_launch, 1)),
                 "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / max(n_launch, 1), 2), "flops_per_step": fl}

@@ -753,6 +753,91 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_p1_kernel(const GemmArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Half-slab pipeline (experiment, variant 14): the 32 KiB of the default kernel cut into two 16 KiB halves of K = 32, so that one
+// half is always in flight while the other is being multiplied -- the default kernel has nothing in flight while it computes.
+// Same occupancy (4 workgroups per CU), twice the barriers.  64-byte LDS rows: chunk c of row r sits at c ^ ((r >> 1) & 3), which is
+// conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32).
+__global__ __launch_bounds__(256, 4) void gemm_bf16_hs_kernel(const GemmArgs a) {
+    constexpr int ES = 2, TMT = 128, HB = 1024;                 // uint4 per half: (128 + 128) rows x 4 chunks
+    __shared__ uint4 lds[2 * HB];
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    if (a.group_m > 0) {
+        const int per_group = a.group_m * a.nbn;
+        const int gid = vid / per_group, first_m = gid * a.group_m;
+        const int gsz = a.nbm - first_m < a.group_m ? a.nbm - first_m : a.group_m;
+        const int loc = vid - gid * per_group;
+        tile_m = first_m + loc % gsz;
+        tile_n = loc / gsz;
+    }
+    const long long m0 = (long long)tile_m * TMT, n0 = (long long)tile_n * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const long long grp = blockIdx.y;
+    const char* Xg = a.X + grp * a.a_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const long long cshift = grp * a.c_gstride;
+    // staging: one DMA = 16 rows x 64 B; wave w issues row blocks w and w + 4 of X and of W per half
+    const int rl = lane >> 2, p4 = lane & 3;
+    const int sck = (p4 ^ ((rl >> 1) & 3)) * 8;                  // source k offset (elements) of this lane inside a half
+    const char* xsrc[2]; const char* wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        long long m = m0 + 16 * (wave + 4 * i) + rl; if (m > a.M - 1) m = a.M - 1;
+        long long n = n0 + 16 * (wave + 4 * i) + rl; if (n > a.N - 1) n = a.N - 1;
+        xsrc[i] = Xg + row_off(a.xmap, m) * ES;
+        wsrc[i] = Wg + n * a.ldw * ES;
+    }
+    const int nhalf = (int)(a.K / 32);
+    auto issue = [&](int h) {
+        const long long k0 = (long long)h * 32 + sck;
+        long long kx = k0;
+        if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
+        uint4* base = lds + (h & 1) * HB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx * ES), (lds_void*)&base[(wave + 4 * i) * 64], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + k0 * ES), (lds_void*)&base[512 + (wave + 4 * i) * 64], 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)lds;
+    const unsigned sw = (unsigned)((fq ^ ((fr >> 1) & 3)) << 4);
+    const unsigned xoff = (unsigned)((wm * 64 + fr) * 64) + sw;
+    const unsigned woff = (unsigned)(8192 + (wn * 64 + fr) * 64) + sw;
+    issue(0);
+    if (nhalf > 1) issue(1);
+    for (int h = 0; h < nhalf; ++h) {
+        if (h + 1 < nhalf) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");     // half h landed, half h+1 stays in flight
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned hb = lds0 + (unsigned)(h & 1) * (HB * 16);
+        u32x4 xf[4], wf[4];
+        xf[0] = ds_read128<0>(hb + xoff); xf[1] = ds_read128<1024>(hb + xoff); xf[2] = ds_read128<2048>(hb + xoff); xf[3] = ds_read128<3072>(hb + xoff);
+        wf[0] = ds_read128<0>(hb + woff); wf[1] = ds_read128<1024>(hb + woff); wf[2] = ds_read128<2048>(hb + woff); wf[3] = ds_read128<3072>(hb + woff);
+#define OCC_HS_ROW(I, CNT)                                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory");                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                        \
+            acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[I]), __builtin_bit_cast(bf16x8, xf[j]), acc[I][j], 0, 0, 0);
+        OCC_HS_ROW(0, 3) OCC_HS_ROW(1, 2) OCC_HS_ROW(2, 1) OCC_HS_ROW(3, 0)
+#undef OCC_HS_ROW
+        if (h + 2 < nhalf) {
+            asm volatile("s_barrier" ::: "memory");              // every wave has read this half: it can be refilled
+            issue(h + 2);
+        }
+    }
+    gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent multi-stage kernel: one workgroup per CU walks a list of output tiles and keeps ONE slab pipeline running across
 // tile boundaries -- while a tile's epilogue runs, the first NST-1 slabs of the workgroup's next tile are already in flight, so
 // block start-up, first-slab latency and store drain are paid once per launch instead of once per tile.  (Measured on the
@@ -1000,7 +1085,9 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     // 256x128 tiles only pay on large square problems (4096^3: 999 vs 865 TFLOP/s); on the front-end shapes (M = 6368, or N = 512)
     // the 128x128 tile's finer granularity wins by 3-15 % (scripts/bench_gemm.py), so it stays the default there.
     const bool big = d->M >= 4096 && d->N >= 4096 && d->M % 256 == 0;
-    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 13) {
+    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 14) {
+        hipLaunchKernelGGL(gemm_bf16_hs_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 13) {
         a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
         a.ngroups = (int)ng;
         const long long tot = (long long)a.nbm * a.nbn * ng;
@@ -1033,6 +1120,11 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
             if (split > nslab / 8) split = nslab / 8;
             if (split < 1) split = 1;
         }
+        // Under-filled launches with a long K (fc2 at M = 6368: 400 tiles for 1024 workgroup slots, 64 slabs each): the half-slab
+        // pipeline keeps loads in flight under the MFMAs and wins 3-6 % there; with every slot busy the plain kernel is 15-20 % faster.
+        if (split == 1 && variant == 1 && total * ng <= 2ll * cu_count() && nslab >= 32) {
+            hipLaunchKernelGGL(gemm_bf16_hs_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+        } else
         if (split > 1) {
             a.slabs_per_split = (int)occ_cdiv(nslab, split);
             a.ksplit = (int)occ_cdiv(nslab, a.slabs_per_split);
