@@ -128,6 +128,8 @@ def main():
                     "minus RawBoost; encoder = transformer only); prints the same JSON with a different workload name")
     ap.add_argument("--bs", type=int, default=BS, help="per-GPU batch (headline: 32)")
     ap.add_argument("--rawboost", type=int, default=0, help="RawBoost algo 1-8 applied on the GPU inside the timed step (configs[2]: 5)")
+    ap.add_argument("--xlsr", default="300m", choices=["300m", "1b"], help="NOT the headline config with 1b: XLS-R-1B geometry (48 layers, d 1280, heads of 80; "
+                    "BASELINE configs[4] asks for it in fp8 over 8 GPUs -- this runs it in bf16)")
     ap.add_argument("--backend", default="aasist", choices=["aasist", "senet"], help="NOT the headline config with senet: SE-ResNet34 on the XLS-R "
                     "features (models/senet.py ssl_resnet34, loss 0.1 c + 0.9 d as test_dataloader_v2.py:127)")
     ap.add_argument("--no-overlap", action="store_true", help="do not compute the next batch's frozen-front-end features on a side stream "
@@ -146,7 +148,7 @@ def main():
     local = local % max(1, torch.cuda.device_count())       # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cfg = xlsr.XlsrConfig.xlsr_300m()
+    cfg = xlsr.XlsrConfig.xlsr_300m() if args.xlsr == "300m" else xlsr.XlsrConfig.xlsr_1b()
     bs = args.bs
     if args.backend == "senet":
         from occm_amd.models.senet import ssl_resnet34
@@ -242,7 +244,7 @@ def main():
         cpu = cpu_baseline()
     if rank == 0:
         if args.backend == "senet":
-            wl = "XLSR-300M %s frontend + SE-ResNet34 backend, bs=%d per GPU (not a BASELINE config; models/senet.py ssl_resnet34)" % ("fine-tuned" if args.finetune else "frozen", bs)
+            wl = "XLSR-%s %s frontend + SE-ResNet34 backend, bs=%d per GPU (not a BASELINE config; models/senet.py ssl_resnet34)" % (args.xlsr.upper(), "fine-tuned" if args.finetune else "frozen", bs)
         else:
             wl = ("XLSR-300M frozen frontend + AASIST backend, bs=%d per GPU, 64000-sample utterances (BASELINE configs[1])" % bs) if not args.finetune else \
             ("XLSR-300M fine-tuned (%s) + AASIST backend, bs=%d per GPU (BASELINE configs[2]%s)" % (args.finetune, bs, ", RawBoost algo %d on-GPU" % args.rawboost if args.rawboost else " without RawBoost"))
@@ -252,7 +254,7 @@ def main():
                "config": {"workload": wl,
                           "global_batch": bs * world, "samples_per_utt": L_SAMPLES, "parallelism": "dp%d" % world,
                           "frontend": "bf16 MFMA, f32 accumulate, HIP-graph replay" + (", features of step i+1 computed on a side stream during step i's back-end" if overlap else ""), "backend": ("fwd+bwd, f32 storage, bf16-MFMA GEMMs and weight gradients (f32 accumulate), dropout on, Adam lr=1e-5" if args.backend == "aasist"
-                                      else "SE-ResNet34 fwd+bwd, f32 storage, exact-f32 MFMA GEMMs, Adam lr=1e-5"),
+                                      else "SE-ResNet34 fwd+bwd, f32 storage, bf16-MFMA convolutions and weight gradients (f32 accumulate), Adam lr=1e-5"),
                           "loss": "%.1f*compactness + %.1f*descriptiveness (%s)" % (wc, wd, "oc_training.py:380-381" if args.backend == "aasist" else "test_dataloader_v2.py:127"), "final_loss_d": round(loss_d, 5)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))

@@ -355,38 +355,43 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
 // 128 through LDS with the online-softmax recurrence (running max m and sum l per query; the O accumulators are rescaled by
 // 2^(m_old - m_new) when a block raises the max).  The reference scores un-padded, un-masked batch-1 utterances
 // (oc_classifier.py:185-193); nothing here depends on T except the loop count.
+// HD = 64 (XLS-R-300M) or 80 (XLS-R-1B: 1280 / 16 heads): 80 = 2.5 MFMA k-steps -> the third Q fragment is half zero, K rows are
+// 10 chunks of 16 B (a 160-byte row stride is conflict-free for ds_read_b128 as it stands, no swizzle), O has 5 column blocks.
+template <int HD>
 __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
                                                                  int Tn, int H, long long ld_qkv, long long ld_out, float scale, float* __restrict__ lse) {
     constexpr int NP = 4, NK = NP * 32, VS = NK + 4;
-    __shared__ uint4 Ks[NK * 8];
-    __shared__ __attribute__((aligned(16))) unsigned short Vt[64 * VS];
-    const int D = H * 64;
+    constexpr int CH = HD / 8, KS = (HD + 31) / 32, NDT = HD / 16;     // 16-byte chunks per row, QK^T k-steps, 16-column blocks of O
+    __shared__ uint4 Ks[NK * CH];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[HD * VS];
+    const int D = H * HD;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int q0 = blockIdx.y * 64;
-    const unsigned short* base = qkv + (size_t)b * Tn * ld_qkv + (size_t)h * 64;
+    const unsigned short* base = qkv + (size_t)b * Tn * ld_qkv + (size_t)h * HD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int qrow = q0 + wave * 16 + fr;
     const bool active = q0 + wave * 16 < Tn;                 // wave-uniform; inactive waves still help staging and hit the barriers
     const int qld = qrow < Tn ? qrow : Tn - 1;
-    uint4 qf[2];
+    uint4 qf[KS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) qf[s] = *reinterpret_cast<const uint4*>(base + (size_t)qld * ld_qkv + s * 32 + g * 8);
+    for (int s = 0; s < KS; ++s)
+        qf[s] = s * 32 + g * 8 < HD ? *reinterpret_cast<const uint4*>(base + (size_t)qld * ld_qkv + s * 32 + g * 8) : make_uint4(0, 0, 0, 0);
     const float c = scale * 1.44269504088896340736f;
     float m_run = -3.0e38f, l_run = 0.f;
-    af32x4 oacc[4];
+    af32x4 oacc[NDT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (af32x4){0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < NDT; ++dt) oacc[dt] = (af32x4){0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < Tn; k0 += NK) {
         __syncthreads();                                     // previous block fully consumed
-        for (int idx = threadIdx.x; idx < NK * 8; idx += 256) {
-            const int kl = idx >> 3, ch = idx & 7, key = k0 + kl;
+        for (int idx = threadIdx.x; idx < NK * CH; idx += 256) {
+            const int kl = idx / CH, ch = idx - kl * CH, key = k0 + kl;
             uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
             if (key < Tn) {
                 kv = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + D + ch * 8);
                 vv = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + 2 * D + ch * 8);
             }
-            Ks[kl * 8 + (ch ^ (kl & 7))] = kv;
+            Ks[kl * CH + (HD == 64 ? (ch ^ (kl & 7)) : ch)] = kv;
             const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -402,8 +407,9 @@ __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned
             sc[t] = (af32x4){0.f, 0.f, 0.f, 0.f};
             const int kr = t * 16 + fr;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                uint4 kf = Ks[kr * 8 + ((s * 4 + g) ^ (kr & 7))];
+            for (int s = 0; s < KS; ++s) {
+                const int chq = s * 4 + g;
+                uint4 kf = chq < CH ? Ks[kr * CH + (HD == 64 ? (chq ^ (kr & 7)) : chq)] : make_uint4(0, 0, 0, 0);
                 sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<abf16x8*>(&kf), *reinterpret_cast<abf16x8*>(&qf[s]), sc[t], 0, 0, 0);
             }
         }
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned
         for (int r = 0; r < 4; ++r) {                        // O rows are queries 4g + r; their factor lives in the lane with fr == 4g + r
             const float a_q = __shfl(alpha, g * 4 + r, 64);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) oacc[dt][r] *= a_q;
+            for (int dt = 0; dt < NDT; ++dt) oacc[dt][r] *= a_q;
         }
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned
             }
             uint4 pf = make_uint4(pw[0], pw[1], pw[2], pw[3]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < NDT; ++dt) {
                 const unsigned short* vr = Vt + (dt * 16 + fr) * VS + u * 32 + g * 4;
                 const uint2 lo = *reinterpret_cast<const uint2*>(vr);
                 const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
@@ -468,9 +474,9 @@ __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned
         const float iv = __shfl(inv, ql, 64);
         const int q = q0 + wave * 16 + ql;
         if (q < Tn) {
-            unsigned short* orow = out + ((size_t)b * Tn + q) * ld_out + (size_t)h * 64 + fr;
+            unsigned short* orow = out + ((size_t)b * Tn + q) * ld_out + (size_t)h * HD + fr;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) orow[dt * 16] = f32_to_bf16_bits(oacc[dt][r] * iv);
+            for (int dt = 0; dt < NDT; ++dt) orow[dt * 16] = f32_to_bf16_bits(oacc[dt][r] * iv);
         }
     }
 }
@@ -540,10 +546,14 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
         OCC_LAUNCH_CHECK("occ_attention(mfma)");
         return OCC_OK;
     }
-    if (dtype == OCC_BF16 && hd == 64 && ld_qkv % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) {       // any T: keys streamed in blocks
+    if (dtype == OCC_BF16 && (hd == 64 || hd == 80) && ld_qkv % 8 == 0 && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) {   // any T: keys streamed in blocks
         const dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64)), block(256);
-        hipLaunchKernelGGL(attention_mfma_long_kernel, grid, block, 0, s, (const unsigned short*)qkv, (unsigned short*)out, (int)T, (int)H, (long long)ld_qkv,
-                           (long long)ld_out, scale, lse);
+        if (hd == 64)
+            hipLaunchKernelGGL(attention_mfma_long_kernel<64>, grid, block, 0, s, (const unsigned short*)qkv, (unsigned short*)out, (int)T, (int)H, (long long)ld_qkv,
+                               (long long)ld_out, scale, lse);
+        else
+            hipLaunchKernelGGL(attention_mfma_long_kernel<80>, grid, block, 0, s, (const unsigned short*)qkv, (unsigned short*)out, (int)T, (int)H, (long long)ld_qkv,
+                               (long long)ld_out, scale, lse);
         OCC_LAUNCH_CHECK("occ_attention(mfma, long)");
         return OCC_OK;
     }

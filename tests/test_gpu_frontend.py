@@ -261,3 +261,37 @@ def test_frontend_long_utterance_matches_oracle():
     assert out.shape == ref.shape and out.shape[1] == 649
     err = (out - ref).abs()
     assert float(err.max()) < 6e-2 and float(err.mean()) < 1e-2, (float(err.max()), float(err.mean()))
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 199, 16), (1, 650, 3), (3, 65, 4), (1, 7, 2)])
+def test_attention_head_dim_80(B, T, H):
+    """XLS-R-1B geometry (1280 / 16 heads): head_dim 80 on the streaming MFMA kernel (third k-step half zero, 5 output blocks)."""
+    from occm_amd import ops
+    hd, D = 80, H * 80
+    qkv = _r(B * T, 3 * D, seed=41).bfloat16()
+    q, k, v = [t.float().view(B, T, H, hd).transpose(1, 2) for t in qkv.split(D, dim=1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B * T, D)
+    lse = torch.empty(B * H * T, device="cuda")
+    out = ops.attention(qkv.cuda(), B, T, H, hd, hd ** -0.5, lse=lse)
+    torch.testing.assert_close(out.cpu().float(), ref, rtol=1e-2, atol=1e-2)
+    s2 = q @ k.transpose(-1, -2) * hd ** -0.5 * 1.4426950408889634
+    ref_lse = torch.log2(torch.exp2(s2 - s2.amax(-1, keepdim=True)).sum(-1)) + s2.amax(-1)
+    torch.testing.assert_close(lse.cpu().view(B, H, T), ref_lse, rtol=1e-3, atol=2e-2)
+
+
+def test_xlsr_1b_geometry_frontend_matches_oracle():
+    """Two encoder layers with XLS-R-1B's dimensions (d = 1280, ffn = 5120, 16 heads of 80, 80-channel positional-conv groups) against
+    the fp32 oracle: bf16 bound as for the 300M geometry."""
+    from oracle import xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.models import xlsr
+    kw = dict(dim=1280, ffn=5120, heads=16, layers=2)
+    rcfg, cfg = xlsr_ref.XlsrConfig(**kw), xlsr.XlsrConfig(**kw)
+    p = fill_like(xlsr_ref.param_shapes(rcfg), seed=3)
+    wav = 0.1 * _r(2, 16000, seed=5)
+    with torch.no_grad():
+        ref = xlsr_ref.extract_feat(wav, p, rcfg)
+    out = xlsr.XlsrFrontend(p, cfg, dtype=torch.bfloat16).forward(wav.cuda(), out_dtype=torch.float32).cpu()
+    assert out.shape == ref.shape == (2, 49, 1280)
+    err = (out - ref).abs()
+    assert float(err.max()) < 6e-2 and float(err.mean()) < 1e-2, (float(err.max()), float(err.mean()))
