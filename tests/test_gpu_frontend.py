@@ -295,3 +295,75 @@ def test_xlsr_1b_geometry_frontend_matches_oracle():
     assert out.shape == ref.shape == (2, 49, 1280)
     err = (out - ref).abs()
     assert float(err.max()) < 6e-2 and float(err.mean()) < 1e-2, (float(err.max()), float(err.mean()))
+
+
+def _fuzz_case(rs):
+    """One random occ_gemm problem: 3-level row maps on A / C / R, K-segments, groups, every operand / output / residual dtype."""
+    from occm_amd import ops
+    mode = rs.choice(["f32", "bf16", "f32_as_bf16", "af32_wbf16"])
+    ce = 4 if mode == "f32" else 8
+    G = int(rs.choice([1, 1, 1, 2, 3]))
+    nseg = int(rs.choice([1, 1, 2, 3]))
+    seg_len = int(rs.randint(1, 9)) * ce * (8 if rs.rand() < 0.3 else 1)
+    K = nseg * seg_len
+    N = int(rs.randint(1, 70)) * 4
+    nb, nl, rpl = int(rs.randint(1, 4)), int(rs.randint(1, 6)), int(rs.randint(1, 40))
+    M = nb * nl * rpl
+    # A: rows in lines in batches, row stride >= seg_len (overlapping windows allowed when nseg == 1), padded strides
+    rstride = int(rs.choice([seg_len, seg_len + ce, ce])) if nseg == 1 else seg_len + ce * int(rs.randint(0, 3))
+    seg_stride = (rpl * rstride + seg_len + ce * int(rs.randint(0, 3))) if nseg > 1 else 0
+    lstride = (rpl - 1) * rstride + K + seg_stride * (nseg - 1) + ce * int(rs.randint(0, 4))
+    lstride = (lstride + ce - 1) // ce * ce
+    bstride = nl * lstride + ce * int(rs.randint(0, 4)) + seg_stride * nseg
+    gstride_a = (nb * bstride + 2 * K + ce - 1) // ce * ce
+    a_len = G * gstride_a + K + seg_stride * nseg
+    a_f = torch.from_numpy(rs.randn(a_len).astype("float32"))
+    w_f = torch.from_numpy((rs.randn(G, N, K) / K ** 0.5).astype("float32"))
+    bias = torch.from_numpy(rs.randn(G * N).astype("float32")) if rs.rand() < 0.7 else None
+    act = rs.choice([ops.ACT_NONE, ops.ACT_GELU, ops.ACT_RELU, ops.ACT_TANH])
+    alpha = float(rs.choice([1.0, 1.0, 0.5]))
+    c_bf, r_kind = rs.rand() < 0.5, rs.choice(["none", "f32", "bf16"])
+    ldc = G * N + 4 * int(rs.randint(0, 3))
+    c_rows = nb * nl * rpl
+    r_f = torch.from_numpy(rs.randn(c_rows, ldc).astype("float32"))
+    a_dev = a_f.bfloat16() if mode == "bf16" else a_f
+    w_dev = w_f.bfloat16() if mode in ("bf16", "af32_wbf16") else w_f
+    # reference operands as the kernel sees them
+    a_ref = a_f.bfloat16().float() if mode != "f32" else a_f
+    w_ref = w_f.bfloat16().float() if mode != "f32" else w_f
+    rows = []
+    for g in range(G):
+        for m in range(M):
+            b, rem = divmod(m, nl * rpl); l, r = divmod(rem, rpl)
+            base = g * gstride_a + b * bstride + l * lstride + r * rstride
+            rows.append(torch.cat([a_ref[base + sgi * seg_stride: base + sgi * seg_stride + seg_len] for sgi in range(nseg)]))
+    A = torch.stack(rows).view(G, M, K).double()
+    ref = alpha * torch.einsum("gmk,gnk->gmn", A, w_ref.double())
+    if bias is not None:
+        ref = ref + bias.view(G, 1, N).double()
+    ref = {ops.ACT_NONE: lambda v: v, ops.ACT_GELU: lambda v: F.gelu(v), ops.ACT_RELU: torch.relu, ops.ACT_TANH: torch.tanh}[act](ref)
+    ref = ref.permute(1, 0, 2).reshape(M, G * N)
+    R = None
+    if r_kind != "none":
+        R = (r_f.bfloat16() if r_kind == "bf16" else r_f)
+        ref = ref + R[:, :G * N].double()
+    C = torch.full((c_rows, ldc), 7.0, dtype=torch.bfloat16 if c_bf else torch.float32).cuda()
+    codes = {"f32": ops.OCC_F32, "bf16": ops.OCC_BF16, "f32_as_bf16": ops.OCC_F32_AS_BF16, "af32_wbf16": ops.OCC_AF32_WBF16}
+    Rd = R.cuda() if R is not None else None
+    ad, wd = a_dev.cuda(), w_dev.contiguous().cuda()
+    ops.gemm_raw(M, N, K, ad, ops.rowmap(nl * rpl, bstride, rstride, rpl, lstride), wd, K, C, ops.rowmap(c_rows, 0, ldc), ops.OCC_BF16 if c_bf else ops.OCC_F32,
+                 codes[mode], bias=bias.cuda() if bias is not None else None, act=act, alpha=alpha, R=Rd, r_map=None if Rd is None else ops.rowmap(c_rows, 0, ldc),
+                 r_dtype=ops.OCC_BF16 if r_kind == "bf16" else ops.OCC_F32, a_seg=(nseg, seg_len, seg_stride) if nseg > 1 else None,
+                 groups=(G, gstride_a, N * K, N) if G > 1 else None)
+    got = C.cpu().double()
+    tol = (2e-5 if mode == "f32" else 3e-3) * max(1.0, float(ref.abs().max())) + (1e-2 * float(ref.abs().max()) if c_bf else 0.0)
+    assert float((got[:, :G * N] - ref).abs().max()) <= tol, (mode, M, N, K, G, nseg, act, c_bf, r_kind, float((got[:, :G * N] - ref).abs().max()), tol)
+    if ldc > G * N:
+        assert bool((got[:, G * N:] == 7.0).all()), "columns outside N were written"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_gemm_fuzz_row_maps_segments_groups_dtypes(seed):
+    rs = np.random.RandomState(1000 + seed)
+    for _ in range(6):
+        _fuzz_case(rs)
