@@ -357,13 +357,18 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
 // (oc_classifier.py:185-193); nothing here depends on T except the loop count.
 // HD = 64 (XLS-R-300M) or 80 (XLS-R-1B: 1280 / 16 heads): 80 = 2.5 MFMA k-steps -> the third Q fragment is half zero, K rows are
 // 10 chunks of 16 B (a 160-byte row stride is conflict-free for ds_read_b128 as it stands, no swizzle), O has 5 column blocks.
+typedef __attribute__((ext_vector_type(4))) short att_s16x4;
+typedef __attribute__((address_space(3))) att_s16x4 att_lds_s16x4;
 template <int HD>
 __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
                                                                  int Tn, int H, long long ld_qkv, long long ld_out, float scale, float* __restrict__ lse) {
-    constexpr int NP = 4, NK = NP * 32, VS = NK + 4;
+    constexpr int NP = 4, NK = NP * 32;
     constexpr int CH = HD / 8, KS = (HD + 31) / 32, NDT = HD / 16;     // 16-byte chunks per row, QK^T k-steps, 16-column blocks of O
     __shared__ uint4 Ks[NK * CH];
-    __shared__ __attribute__((aligned(16))) unsigned short Vt[HD * VS];
+    // V stays row-major ([key][d], 160-byte rows: 128 or 160 data bytes); its MFMA fragments (8 keys per lane) are read with the
+    // transposing ds_read_b64_tr_b16 -- the 8 consecutive rows a 32-lane half touches fall on disjoint bank octets at this stride
+    constexpr int VROW = 160;
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[NK * VROW];
     const int D = H * HD;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int q0 = blockIdx.y * 64;
@@ -392,12 +397,7 @@ __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned
                 vv = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + 2 * D + ch * 8);
             }
             Ks[kl * CH + (HD == 64 ? (ch ^ (kl & 7)) : ch)] = kv;
-            const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                Vt[(ch * 8 + 2 * e) * VS + kl] = (unsigned short)(w[e] & 0xffff);
-                Vt[(ch * 8 + 2 * e + 1) * VS + kl] = (unsigned short)(w[e] >> 16);
-            }
+            *reinterpret_cast<uint4*>(Vs + kl * VROW + ch * 16) = vv;
         }
         __syncthreads();
         if (!active) continue;
@@ -457,11 +457,12 @@ __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned
             uint4 pf = make_uint4(pw[0], pw[1], pw[2], pw[3]);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                const unsigned short* vr = Vt + (dt * 16 + fr) * VS + u * 32 + g * 4;
-                const uint2 lo = *reinterpret_cast<const uint2*>(vr);
-                const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
-                uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<abf16x8*>(&pf), *reinterpret_cast<abf16x8*>(&vf), oacc[dt], 0, 0, 0);
+                // k-slots 0-3 <-> keys u*32 + 4g + q, k-slots 4-7 <-> keys u*32 + 16 + 4g + q (the packing of P above); columns dt*16 ..
+                const unsigned char* vr = Vs + (u * 32 + 4 * g + (fr >> 2)) * VROW + (dt * 16 + (fr & 3) * 4) * 2;
+                const att_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s16x4*)vr);
+                const att_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s16x4*)(vr + 16 * VROW));
+                const abf16x8 vf = __builtin_bit_cast(abf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<abf16x8*>(&pf), vf, oacc[dt], 0, 0, 0);
             }
         }
     }
