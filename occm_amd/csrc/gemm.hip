@@ -753,6 +753,129 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_p1_kernel(const GemmArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Deep half-slab pipeline on a big tile (experiment, variant 15/16): block tile (WGM*NJ*16) x (WGN*64), K advanced in steps of 32
+// through NST LDS stages of (TMB + TNB) x 64 B; NST-1 steps are in flight, the wait is a counted vmcnt, the barriers are raw.
+// At 256x256 (8 waves, 128x64 per wave): 32 KiB per stage, 4 stages = 128 KiB, 96 KiB in flight per CU at 128 FLOP per L2 byte.
+template <int WGM, int WGN, int NJ, int NST>
+__global__ __launch_bounds__(WGM * WGN * 64, 1) void gemm_bf16_ms32_kernel(const GemmArgs a) {
+    constexpr int ES = 2;
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int TMB = WGM * NJ * 16, TNB = WGN * 64;
+    constexpr int RPP = NT / 4;                       // rows staged per pass (one DMA = 16 rows x 64 B)
+    constexpr int XP = TMB / RPP, WP = TNB / RPP;
+    constexpr int PER = XP + WP;
+    constexpr int STAGE = (TMB + TNB) * 4;            // uint4 per stage
+    static_assert(TMB % RPP == 0 && TNB % RPP == 0 && (NST - 2) * PER <= 63, "tile / vmcnt");
+    extern __shared__ uint4 plds[];
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    if (a.group_m > 0) {
+        const int per_group = a.group_m * a.nbn;
+        const int gid = vid / per_group, first_m = gid * a.group_m;
+        const int gsz = a.nbm - first_m < a.group_m ? a.nbm - first_m : a.group_m;
+        const int loc = vid - gid * per_group;
+        tile_m = first_m + loc % gsz;
+        tile_n = loc / gsz;
+    }
+    const long long m0 = (long long)tile_m * TMB, n0 = (long long)tile_n * TNB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WGM, wn = wave / WGM;
+    const long long grp = blockIdx.y;
+    const char* Xg = a.X + grp * a.a_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const long long cshift = grp * a.c_gstride;
+    const int srow = tid >> 2, p4 = tid & 3;          // staging: thread -> (row inside a pass, 16-byte position)
+    const int sck = (p4 ^ ((srow >> 1) & 3)) * 8;     // RPP % 8 == 0: same source chunk for every pass
+    const char* xsrc[XP]; const char* wsrc[WP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        long long m = m0 + srow + RPP * i; if (m > a.M - 1) m = a.M - 1;
+        xsrc[i] = Xg + row_off(a.xmap, m) * ES;
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        long long n = n0 + srow + RPP * i; if (n > a.N - 1) n = a.N - 1;
+        wsrc[i] = Wg + n * a.ldw * ES;
+    }
+    const int nstep = (int)(a.K / 32);
+    auto stage = [&](int h, int buf) {
+        uint4* sx = plds + buf * STAGE;
+        uint4* sw = sx + TMB * 4;
+        const long long k0 = (long long)h * 32 + sck;
+        long long kx = k0;
+        if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
+#pragma unroll
+        for (int i = 0; i < XP; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx * ES), (lds_void*)&sx[(wave * 16 + RPP * i) * 4], 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + k0 * ES), (lds_void*)&sw[(wave * 16 + RPP * i) * 4], 16, 0, 0);
+    };
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)plds;
+    const unsigned sw16 = (unsigned)((fq ^ ((fr >> 1) & 3)) << 4);
+    const unsigned xoff = (unsigned)((wm * (NJ * 16) + fr) * 64) + sw16;
+    const unsigned woff = (unsigned)(TMB * 64 + (wn * 64 + fr) * 64) + sw16;
+#pragma unroll
+    for (int h = 0; h < NST - 1; ++h)
+        if (h < nstep) stage(h, h);
+    int buf = 0, nbuf = NST - 1;
+    for (int h = 0; h < nstep; ++h) {
+        const int later = nstep - 1 - h;
+        if (later >= NST - 2) wait_vm_then_barrier<(NST - 2) * PER>();
+        else if (NST > 3 && later == 2) wait_vm_then_barrier<2 * PER>();
+        else if (NST > 3 && later == 1) wait_vm_then_barrier<PER>();
+        else wait_vm_then_barrier<0>();
+        if (h + NST - 1 < nstep) stage(h + NST - 1, nbuf);     // the stage of step h-1: every wave has passed the barrier after reading it
+        const unsigned sb = lds0 + (unsigned)buf * (STAGE * 16);
+        u32x4 wf[4], xf[NJ];
+        wf[0] = ds_read128<0>(sb + woff); wf[1] = ds_read128<1024>(sb + woff); wf[2] = ds_read128<2048>(sb + woff); wf[3] = ds_read128<3072>(sb + woff);
+        xf[0] = ds_read128<0>(sb + xoff); xf[1] = ds_read128<1024>(sb + xoff); xf[2] = ds_read128<2048>(sb + xoff); xf[3] = ds_read128<3072>(sb + xoff);
+        if constexpr (NJ == 8) {
+            xf[4] = ds_read128<4096>(sb + xoff); xf[5] = ds_read128<5120>(sb + xoff); xf[6] = ds_read128<6144>(sb + xoff); xf[7] = ds_read128<7168>(sb + xoff);
+        }
+        // x fragments are consumed column by column: wait only for what the next group of MFMAs needs
+#define OCC_MS32_COL(J, CNT)                                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory");                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                        \
+            acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]), __builtin_bit_cast(bf16x8, xf[J]), acc[i][J], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (NJ == 8) { OCC_MS32_COL(0, 7) OCC_MS32_COL(1, 6) OCC_MS32_COL(2, 5) OCC_MS32_COL(3, 4) OCC_MS32_COL(4, 3) OCC_MS32_COL(5, 2) OCC_MS32_COL(6, 1) OCC_MS32_COL(7, 0) }
+        else { OCC_MS32_COL(0, 3) OCC_MS32_COL(1, 2) OCC_MS32_COL(2, 1) OCC_MS32_COL(3, 0) }
+        __builtin_amdgcn_s_setprio(0);
+#undef OCC_MS32_COL
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+    }
+    gemm_epilogue<NJ>(a, acc, m0 + wm * (NJ * 16), n0 + wn * 64, fr, fq, cshift);
+}
+
+template <int WGM, int WGN, int NJ, int NST>
+int launch_ms32(GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_t s) {
+    constexpr int TMB = WGM * NJ * 16, TNB = WGN * 64;
+    a.nbm = (int)occ_cdiv(d->M, TMB); a.nbn = (int)occ_cdiv(d->N, TNB);
+    a.group_m = a.nbn >= 8 ? 4 : 0;
+    const size_t shm = (size_t)NST * (TMB + TNB) * 4 * sizeof(uint4);
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_ms32_kernel<WGM, WGN, NJ, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) { occ_set_error("occ_gemm: cannot raise the LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+        raised = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_ms32_kernel<WGM, WGN, NJ, NST>), dim3((unsigned)((long long)a.nbm * a.nbn), (unsigned)ng), dim3(WGM * WGN * 64), shm, s, a);
+    return OCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Half-slab pipeline (experiment, variant 14): the 32 KiB of the default kernel cut into two 16 KiB halves of K = 32, so that one
 // half is always in flight while the other is being multiplied -- the default kernel has nothing in flight while it computes.
 // Same occupancy (4 workgroups per CU), twice the barriers.  64-byte LDS rows: chunk c of row r sits at c ^ ((r >> 1) & 3), which is
@@ -1085,7 +1208,10 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     // 256x128 tiles only pay on large square problems (4096^3: 999 vs 865 TFLOP/s); on the front-end shapes (M = 6368, or N = 512)
     // the 128x128 tile's finer granularity wins by 3-15 % (scripts/bench_gemm.py), so it stays the default there.
     const bool big = d->M >= 4096 && d->N >= 4096 && d->M % 256 == 0;
-    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 14) {
+    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 15 || variant == 16)) {
+        const int rc = variant == 15 ? launch_ms32<2, 4, 8, 4>(a, d, ng, s) : launch_ms32<4, 2, 4, 5>(a, d, ng, s);
+        if (rc != OCC_OK) return rc;
+    } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 14) {
         hipLaunchKernelGGL(gemm_bf16_hs_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 13) {
         a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
