@@ -1,0 +1,217 @@
+// Shared pieces of the occ_gemm kernel family (gemm.hip: the product kernels and the occ_gemm entry point;
+// gemm_family.hip: the experimental kernels behind occ_gemm_variant): argument block, epilogues, LDS-DMA / fragment-read helpers.
+#pragma once
+#include "occ_common.h"
+#include <stdlib.h>
+
+namespace occ_gemm_detail {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int TM = 128, TN = 128, THREADS = 256;
+constexpr int SLAB_BYTES = 128;                 // K bytes per row per slab
+constexpr int CHUNKS = SLAB_BYTES / 16;         // 8 chunks of 16 B per row
+
+struct GemmArgs {
+    long long M, N, K;
+    const char* X; RowMapI xmap; long long nseg, seg_len, seg_stride;
+    const char* W; long long ldw;
+    const float* bias;
+    const char* R; RowMapI rmap; int r_dtype;
+    char* C; RowMapI cmap; int c_dtype;
+    int act; float alpha;
+    unsigned short* aux;
+    int nbm, nbn;
+    int group_m;              // >0: walk GROUP_M m-tiles per n-tile before moving on (L2-sized working set), 0: n fastest
+    long long a_gstride, w_gstride, c_gstride;
+    int ngroups;             // persistent kernel: groups folded into the tile id
+    int ksplit;              // > 1: the K range is cut into ksplit pieces handled by different workgroups, C += alpha*acc with f32 atomics
+    int slabs_per_split;
+    int dbg;                 // ablation bits (timing experiments only, results wrong): 1 no loads in the K loop, 2 no MFMA, 4 no fragment reads
+};
+
+__device__ __forceinline__ float act_rt(int act, float v) {
+    switch (act) {
+        case OCC_ACT_GELU: return gelu_erf(v);
+        case OCC_ACT_SELU: return selu_f(v);
+        case OCC_ACT_RELU: return v > 0.f ? v : 0.f;
+        case OCC_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+// Straight-line epilogue for the combinations launched thousands of times per step (no side
+// tensor, activation none / GELU, residual none / f32): everything wave-uniform is a template parameter, the bias row is loaded
+// once per 16-column block instead of once per 16x16 block.  The generic gemm_epilogue below handles every other combination
+// with run-time switches; on the 128x128 tile that code executed ~1500 instructions per thread, which (with the workgroups of a
+// round reaching it together) was a third of a K = 1024 GEMM's run time.
+template <int NJ, bool HASB, bool GELU, bool HASR, bool CBF>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
+                                                   const f32x4* breg) {
+    f32x4 bv[4];
+    if (HASB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (breg) { bv[i] = breg[i]; continue; }
+            long long n = ncol0 + i * 16 + fq * 4; if (n > a.N - 4) n = a.N - 4;       // N % 4 == 0; out-of-range columns are never stored
+            bv[i] = *reinterpret_cast<const f32x4*>(a.bias + cshift + n);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long m = mrow0 + j * 16 + fr;
+        if (m >= a.M) continue;
+        const long long coff = row_off(a.cmap, m) + cshift;
+        const long long roff = HASR ? row_off(a.rmap, m) + cshift : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long n = ncol0 + i * 16 + fq * 4;
+            if (n >= a.N) continue;
+            f32x4 v = acc[i][j];
+            if (HASB) v += bv[i];
+            if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            if (HASR) v += *reinterpret_cast<const f32x4*>(a.R + (roff + n) * 4);
+            if (CBF) {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2*>(a.C + (coff + n) * 2) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(a.C + (coff + n) * 4) = v;
+            }
+        }
+    }
+}
+
+// Split-K epilogue: C (f32) += alpha * acc with float atomics; used for weight-gradient GEMMs whose output has only a few dozen
+// tiles while K is the whole batch (the caller passes R == C, i.e. "accumulate"; the pieces add onto what C holds).
+template <int NJ>
+__device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long m = mrow0 + j * 16 + fr;
+        if (m >= a.M) continue;
+        float* crow = reinterpret_cast<float*>(a.C) + row_off(a.cmap, m) + cshift;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long n = ncol0 + i * 16 + fq * 4;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(crow + n + e, acc[i][j][e] * a.alpha);
+        }
+    }
+}
+
+// acc[i][j]: i = 16-column block of the wave's 64 output columns, j = 16-row block of its NJ*16 output rows;
+// mrow0 / ncol0 = first row / column of the wave's sub-tile.  A lane owns C[m][n..n+3].
+template <int NJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
+                                              const f32x4* breg = nullptr) {
+    if (a.alpha == 1.0f && !a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU) && (!a.R || a.r_dtype == OCC_F32)) {
+        // wave-uniform flags -> one scalar branch chain into a straight-line instantiation
+        const int key = (a.bias ? 8 : 0) | (a.act == OCC_ACT_GELU ? 4 : 0) | (a.R ? 2 : 0) | (a.c_dtype != OCC_F32 ? 1 : 0);
+#define OCC_EPI(K, B, G, R, C) case K: gemm_epilogue_fast<NJ, B, G, R, C>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); break;
+        switch (key) {
+            OCC_EPI(0, false, false, false, false) OCC_EPI(1, false, false, false, true) OCC_EPI(2, false, false, true, false) OCC_EPI(3, false, false, true, true)
+            OCC_EPI(4, false, true, false, false) OCC_EPI(5, false, true, false, true) OCC_EPI(6, false, true, true, false) OCC_EPI(7, false, true, true, true)
+            OCC_EPI(8, true, false, false, false) OCC_EPI(9, true, false, false, true) OCC_EPI(10, true, false, true, false) OCC_EPI(11, true, false, true, true)
+            OCC_EPI(12, true, true, false, false) OCC_EPI(13, true, true, false, true) OCC_EPI(14, true, true, true, false) OCC_EPI(15, true, true, true, true)
+        }
+#undef OCC_EPI
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long m = mrow0 + j * 16 + fr;
+        if (m >= a.M) continue;
+        const long long coff = row_off(a.cmap, m) + cshift;
+        const long long roff = a.R ? row_off(a.rmap, m) + cshift : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long n = ncol0 + i * 16 + fq * 4;
+            if (n >= a.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * a.alpha;
+            if (breg) {                                                 // bias already in registers (staged through LDS by the caller)
+                v[0] += breg[i][0]; v[1] += breg[i][1]; v[2] += breg[i][2]; v[3] += breg[i][3];
+            } else if (a.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + cshift + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            if (a.aux && a.act == OCC_ACT_GELU) {                       // keep the pre-activation for backward
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2*>(a.aux + coff + n) = o;
+            }
+            if (a.act == OCC_ACT_GELU_GRAD) {
+                const uint2 u = *reinterpret_cast<const uint2*>(a.aux + coff + n);
+                v[0] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x & 0xffff))); v[1] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x >> 16)));
+                v[2] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y & 0xffff))); v[3] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y >> 16)));
+            } else if (a.act != OCC_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_rt(a.act, v[e]);
+            }
+            if (a.R) {
+                if (a.r_dtype == OCC_F32) {
+                    const float4 rv = *reinterpret_cast<const float4*>(a.R + (roff + n) * 4);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                } else {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(a.R + (roff + n) * 2);
+                    v[0] += bf16_bits_to_f32((unsigned short)(rv.x & 0xffff)); v[1] += bf16_bits_to_f32((unsigned short)(rv.x >> 16));
+                    v[2] += bf16_bits_to_f32((unsigned short)(rv.y & 0xffff)); v[3] += bf16_bits_to_f32((unsigned short)(rv.y >> 16));
+                }
+            }
+            if (a.c_dtype == OCC_F32) {
+                *reinterpret_cast<float4*>(a.C + (coff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2*>(a.C + (coff + n) * 2) = o;
+            }
+        }
+    }
+}
+
+// MODE 0: f32 operands, exact-f32 MFMA.  MODE 1: bf16 operands, bf16 MFMA.  MODE 2: f32 operands in memory, rounded to
+// bf16 while they are staged into LDS, bf16 MFMA (f32 accumulate) -- the back-end's "bf16 compute" mode, which
+// needs no bf16 copies of f32 activations / gradients.
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int OFF> __device__ __forceinline__ u32x4 ds_read128(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// N fragments of 16 rows each, 2 KiB apart (16 rows x 128 B)
+template <int N> __device__ __forceinline__ void read_frags(u32x4 (&f)[N], unsigned addr) {
+    f[0] = ds_read128<0>(addr); f[1] = ds_read128<2048>(addr); f[2] = ds_read128<4096>(addr); f[3] = ds_read128<6144>(addr);
+    if constexpr (N == 8) {
+        f[4] = ds_read128<8192>(addr); f[5] = ds_read128<10240>(addr); f[6] = ds_read128<12288>(addr); f[7] = ds_read128<14336>(addr);
+    }
+}
+template <int N> __device__ __forceinline__ void wait_vm_then_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+inline int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+
+// experimental kernels (gemm_family.hip); returns -100 when `variant` is not one of them, else OCC_OK / an error status
+int gemm_family_launch(int variant, GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_t s);
+
+}  // namespace occ_gemm_detail
