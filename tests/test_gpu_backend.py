@@ -428,3 +428,58 @@ def test_gemm_tn_dma_conv_windows():
               bf16_mfma=True)
     ref = dy.double().T @ win.double()
     torch.testing.assert_close(C.cpu().double(), ref, rtol=1e-4, atol=2e-6 * float(ref.abs().max()) + 2e-4)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gemm_tn_fuzz(seed):
+    """Random weight-gradient problems over the three occ_gemm_tn kernels (exact f32, bf16 MFMA, LDS-DMA bf16): 3-level row maps on
+    both operands, B K-segments, ragged M / N1 / N2, accumulation onto existing C, fused bias gradient."""
+    from occm_amd import backend_ops as K
+    rs = np.random.RandomState(500 + seed)
+    for _ in range(4):
+        kind = rs.choice(["f32", "bf16_mfma", "dma"])
+        unit = 8 if kind == "dma" else 4
+        nb, nl, rpl = int(rs.randint(1, 4)), int(rs.randint(1, 5)), int(rs.randint(8, 60))
+        M = nb * nl * rpl
+        if kind == "dma":
+            M = max(M, 256); nb, nl, rpl = 1, 1, M
+        N1 = int(rs.randint(16, 40)) * unit if kind == "dma" else int(rs.randint(1, 40)) * unit
+        nseg = int(rs.choice([1, 1, 2, 3]))
+        seg_len = (128 * int(rs.randint(1, 3))) if (kind == "dma" and nseg > 1) else int(rs.randint(2, 24)) * unit
+        if kind == "dma" and nseg == 1:
+            seg_len = max(seg_len, 128)
+        N2 = nseg * seg_len
+        a_rs = N1 + unit * int(rs.randint(0, 3))
+        a_ls = rpl * a_rs + unit * int(rs.randint(0, 3))
+        a_bs = nl * a_ls + unit * int(rs.randint(0, 3))
+        b_rs = int(rs.choice([seg_len, unit, seg_len + unit])) if nseg == 1 else seg_len + unit * int(rs.randint(0, 2))
+        seg_stride = rpl * b_rs + seg_len + unit * int(rs.randint(0, 3)) if nseg > 1 else 0
+        b_ls = (rpl - 1) * b_rs + N2 + seg_stride * nseg + unit * int(rs.randint(0, 3))
+        b_ls = (b_ls + unit - 1) // unit * unit
+        b_bs = nl * b_ls + unit * int(rs.randint(0, 3))
+        a_buf = torch.from_numpy(rs.randn(nb * a_bs + N1).astype("float32"))
+        b_buf = torch.from_numpy(rs.randn(nb * b_bs + N2 + seg_stride * nseg).astype("float32"))
+        bf = kind == "dma"
+        a_dev, b_dev = (a_buf.bfloat16(), b_buf.bfloat16()) if bf else (a_buf, b_buf)
+        a_ref, b_ref = (a_buf.bfloat16().float(), b_buf.bfloat16().float()) if kind != "f32" else (a_buf, b_buf)
+        a_src = a_buf.bfloat16().float() if bf else a_buf
+        ar, br, ar_src = [], [], []
+        for m in range(M):
+            b, rem = divmod(m, nl * rpl); l, r = divmod(rem, rpl)
+            ao = b * a_bs + l * a_ls + r * a_rs
+            bo = b * b_bs + l * b_ls + r * b_rs
+            ar.append(a_ref[ao: ao + N1]); ar_src.append(a_src[ao: ao + N1])
+            br.append(torch.cat([b_ref[bo + s * seg_stride: bo + s * seg_stride + seg_len] for s in range(nseg)]))
+        A, Bm = torch.stack(ar).double(), torch.stack(br).double()
+        ldc = N2 + 4 * int(rs.randint(0, 3))
+        c0 = torch.from_numpy(rs.randn(N1, ldc).astype("float32"))
+        C, cs = c0.clone().cuda(), torch.zeros(N1).cuda()
+        alpha = float(rs.choice([1.0, 0.25]))
+        K.gemm_tn(M, N1, N2, a_dev.cuda(), K.rowmap(nl * rpl, a_bs, a_rs, rpl, a_ls), b_dev.cuda(), K.rowmap(nl * rpl, b_bs, b_rs, rpl, b_ls), C, ldc,
+                  b_seg=(nseg, seg_len, seg_stride) if nseg > 1 else None, alpha=alpha, colsum_out=cs, a_bf16=bf, b_bf16=bf, bf16_mfma=kind != "f32")
+        ref = c0.double()
+        ref[:, :N2] += alpha * (A.T @ Bm)
+        tol = 2e-5 * float(ref.abs().max()) + 3e-4
+        assert float((C.cpu().double() - ref).abs().max()) <= tol, (kind, M, N1, N2, nseg, float((C.cpu().double() - ref).abs().max()), tol)
+        sref = alpha * torch.stack(ar_src).double().sum(0)          # the bias gradient sums the operand as stored (un-rounded f32, or the bf16 values)
+        torch.testing.assert_close(cs.cpu().double(), sref, rtol=1e-4, atol=2e-3)
