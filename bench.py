@@ -230,7 +230,7 @@ def main():
         traffic, tnote = None, None
         try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
-            ks = [v for k, v in pm["kernels"].items() if k.startswith("gemm_bf16_")]          # the bf16 GEMM family (default + half-slab kernels)
+            ks = [v for k, v in pm["kernels"].items() if "gemm_bf16_" in k]          # the bf16 GEMM family (default + half-slab kernels)
             traffic = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks))
             tnote = "profiles/r01_pmc_hbm.json (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE)"
         except (OSError, KeyError, ValueError):

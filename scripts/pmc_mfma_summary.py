@@ -5,7 +5,7 @@ import collections, csv, json, re, sys
 util, act = collections.defaultdict(dict), collections.defaultdict(dict)
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        k = re.sub(r"^void ", "", re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0])
+        k = re.sub(r"^void ", "", re.sub(r"(\(anonymous namespace\)|occ_gemm_detail)::", "", r["Kernel_Name"]).split("(")[0])
         d = r.get("Dispatch_Id") or r.get("Correlation_Id")
         if r["Counter_Name"] == "MfmaUtil":
             util[k][d] = util[k].get(d, 0.0) + float(r["Counter_Value"])

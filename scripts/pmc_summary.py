@@ -11,7 +11,7 @@ def load(path, counter):
         for r in csv.DictReader(f):
             if r.get("Counter_Name") != counter:
                 continue
-            k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0]
+            k = re.sub(r"(\(anonymous namespace\)|occ_gemm_detail)::", "", r["Kernel_Name"]).split("(")[0]
             k = re.sub(r"^void ", "", k)
             tot[k] += float(r["Counter_Value"]); cnt[k] += 1
     return tot, cnt

@@ -8,7 +8,7 @@ with open(path) as f:
         name = r["Kernel_Name"]
         if pat and not re.search(pat, name):
             continue
-        short = re.sub(r"\(anonymous namespace\)::", "", name).split("(")[0][-60:]
+        short = re.sub(r"(\(anonymous namespace\)|occ_gemm_detail)::", "", name).split("(")[0][-60:]
         key = (short, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")))
         rows[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = sum(sum(v) for v in rows.values())
