@@ -23,7 +23,11 @@ def calculate_EER(eval_protocol_file, score_file, verbose=True):
             parts = line.split()
             if len(parts) < 2 or parts[0] not in labels:
                 continue
-            (spoof if labels[parts[0]] == "spoof" else bona).append(float(parts[1]))
+            lab = labels[parts[0]]                          # the reference selects exactly these two label strings (:21-22)
+            if lab == "spoof":
+                spoof.append(float(parts[1]))
+            elif lab == "bonafide":
+                bona.append(float(parts[1]))
     eer, threshold = compute_eer(np.array(bona), np.array(spoof))   # calculate_eer.py:25 argument order
     if verbose:
         print(f"EER = {eer*100.0}, threshold = {threshold}")
