@@ -108,7 +108,16 @@ def main(argv=None):
     parser.add_argument("--rawboost_algo", type=int, default=0)
     parser.add_argument("--ssl_checkpoint", type=str, default=None, help="torch file with fairseq-named XLS-R weights")
     parser.add_argument("--wandb", action="store_true")
+    # not in the reference: the back-end class (its --model flag is parsed but never read: oc_training.py:320 always builds AModel),
+    # loader workers (the reference uses num_workers=0; at thousands of utterances/s the decode has to run ahead of the GPU)
+    parser.add_argument("--backend", type=str, default="aasist", choices=["aasist", "senet"])
+    parser.add_argument("--num_workers", type=int, default=0)
+    parser.add_argument("--rawboost_on_gpu", action="store_true", help="apply --rawboost_algo to the whole group in one batched device call inside the "
+                        "training step (Philox parameter draws) instead of per utterance in the dataset (np.random draws in the reference's order); "
+                        "the batched form also perturbs the zero-padded tails of the shorter utterances of a group")
     args = parser.parse_args(argv)
+    if args.num_workers > 0 and args.rawboost_algo and not args.rawboost_on_gpu:
+        raise ValueError("dataset-side RawBoost runs on the GPU of the main process: use --num_workers 0 or --rawboost_on_gpu")
     print("*************************************************")
     for k in ("train_dataset_dir", "test_dataset_dir", "model", "finetuned", "train_protocol_file", "test_protocol_file"):
         print(f"{k} = {getattr(args, k)}")
@@ -120,16 +129,26 @@ def main(argv=None):
     rank, world, local = parallel.init_from_env()
     device = torch.device("cuda", local)
     torch.cuda.set_device(local)
-    dataset = PFDataset(args.train_protocol_file, args.train_dataset_dir, vocoded_dir=args.vocoded_dir, rawboost_algo=args.rawboost_algo)
+    dataset = PFDataset(args.train_protocol_file, args.train_dataset_dir, vocoded_dir=args.vocoded_dir,
+                        rawboost_algo=0 if args.rawboost_on_gpu else args.rawboost_algo)
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, world, rank, shuffle=True) if world > 1 else None
-    loader = DataLoader(dataset, batch_size=1, shuffle=sampler is None, sampler=sampler, num_workers=0)
+    loader = DataLoader(dataset, batch_size=1, shuffle=sampler is None, sampler=sampler, num_workers=args.num_workers, pin_memory=True,
+                        persistent_workers=args.num_workers > 0, prefetch_factor=4 if args.num_workers > 0 else None)
     ssl_sd = None
     if args.ssl_checkpoint:
         ck = torch.load(args.ssl_checkpoint, map_location="cpu")
         ssl_sd = ck.get("model", ck)
-    model = AModel(None, device, ssl_state_dict=ssl_sd)
+    # --finetuned: train XLS-R end to end as the reference's optimizer does (oc_training.py:324 holds every SSL parameter); without it
+    # the front-end is frozen (BASELINE configs[1]) and its features for the next batch are computed under the current update
+    ft = "full" if args.finetuned else False
+    if args.backend == "senet":
+        from .models.senet import ssl_resnet34
+        model = ssl_resnet34(device, ssl_state_dict=ssl_sd, finetune_ssl=ft)
+    else:
+        model = AModel(None, device, ssl_state_dict=ssl_sd, finetune_ssl=ft)
     model.train()
-    trainer = OcTrainer(model, lr=args.lr, w_compact=args.w_compact, w_descr=args.w_descr, train_frontend=False)
+    trainer = OcTrainer(model, lr=args.lr, w_compact=args.w_compact, w_descr=args.w_descr, train_frontend=bool(ft),
+                        rawboost_algo=args.rawboost_algo if args.rawboost_on_gpu else 0)
     wb = None
     if args.wandb and rank == 0:
         import wandb as wb
