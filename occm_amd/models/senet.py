@@ -512,3 +512,17 @@ class ssl_resnet34(torch.nn.Module):
         feats = self.frontend.model.forward(x, out_dtype=torch.float32)
         self.resnet34.train(self.training)
         return self.resnet34(feats.unsqueeze(1))
+
+    def state_dict(self, *a, **kw):
+        """Keys as the reference module tree gives them (senet.py:165-166): ``resnet34.*`` and ``frontend.model.*`` (fairseq names)."""
+        sd = {"resnet34." + k: v for k, v in self.resnet34.state_dict().items()}
+        ssl = dict(self.frontend._params)
+        if getattr(self.frontend, "finetune", False):
+            ssl.update(self.frontend.model.export_params())
+        for k, v in ssl.items():
+            sd["frontend.model." + k] = v.detach().clone() if torch.is_tensor(v) else v
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        self.resnet34.load_state_dict({k[len("resnet34."):]: v for k, v in sd.items() if k.startswith("resnet34.")})
+        return self

@@ -66,3 +66,34 @@ def test_reference_embedding_threshold_and_scores_match_oracle(tmp_path, monkeyp
         od = float(losses_ref.pairwise_l2(o_ref, oracle_emb(str(d / f"E{i}.wav"))))
         assert abs(float(dist) - od) < 2e-3 and line.endswith(" ")
         assert int(flag) == int(float(dist) > float(thr))
+
+
+@pytest.mark.parametrize("extra", [[], ["--backend", "senet"], ["--finetuned"], ["--rawboost_algo", "5", "--rawboost_on_gpu"]])
+def test_oc_training_entry_point_runs_and_saves_checkpoint(tmp_path, monkeypatch, extra):
+    """python -m occm_amd.oc_training on a tiny synthetic corpus (PFDataset groups of 12 from 16-bit wav files): one epoch through the
+    real entry point, checkpoint written under the reference's file name with the reference's key names."""
+    import random
+    from occm_amd import oc_training
+    from occm_amd.models import xlsr
+    from occm_amd.oc_training import VOCODERS
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(xlsr.XlsrConfig, "xlsr_300m", staticmethod(lambda: xlsr.XlsrConfig(dim=1024, ffn=256, heads=16, layers=1)))
+    d, v = tmp_path / "wav", tmp_path / "voc"
+    d.mkdir(); v.mkdir()
+    lines = []
+    for i in range(7):
+        lines.append(f"LA_00{i} B{i} - - bonafide"); _write_wav(str(d / f"B{i}.wav"), 16000 + 300 * i, i)
+        for k, name in enumerate(VOCODERS):
+            _write_wav(str(v / f"{name}_B{i}.wav"), 16000 + 50 * k, 100 + i * 5 + k)
+    for i in range(3):
+        lines.append(f"LA_01{i} S{i} - A0{i} spoof"); _write_wav(str(d / f"S{i}.wav"), 15000 + 11 * i, 50 + i)
+    (tmp_path / "prot.txt").write_text("\n".join(lines) + "\n")
+    random.seed(0); torch.manual_seed(0)
+    oc_training.main(["--train_protocol_file", str(tmp_path / "prot.txt"), "--train_dataset_dir", str(d), "--vocoded_dir", str(v), "--epochs", "1",
+                      "--lr", "1e-4"] + extra)
+    sd = torch.load(str(tmp_path / "aasist_vocoded_0.pt"), map_location="cpu")
+    assert all(torch.isfinite(t.float()).all() for t in sd.values() if torch.is_tensor(t))
+    if "--backend" in extra:
+        assert "layer1.0.conv1.weight" in sd or any(k.endswith("layer1.0.conv1.weight") for k in sd)
+    else:
+        assert "LL.weight" in sd and "out_layer.weight" in sd and any(k.startswith("ssl_model.model.") for k in sd)
