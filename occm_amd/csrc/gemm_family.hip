@@ -594,7 +594,156 @@ int launch_persist(GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Big-register-tile pipeline (experiment, variant 17): 256x256 block tile, FOUR waves (2x2) each owning 128x128 of it (64 accumulators
+// of 16x16 = 256 registers), one workgroup per CU -- the shape the vendor library picks for these problems (hipBLASLt: MT256x256x64,
+// 256 threads, 133 KB LDS).  Idea: with LDS-DMA a CU pulls operands at (bytes in flight) / (load latency) and the LDS bounds the bytes in
+// flight; a 256x256 tile does 128 FLOP per operand byte against the 128x128 tile's 64.  One wave per SIMD hides nothing by occupancy, so the
+// loop is software-pipelined by hand: two LDS stages of one K = 64 slab each (128-byte rows, the default kernel's swizzle), stage s+2 is
+// DMA'd while the second half of stage s is multiplied, the fragments of the next half-slab are read into a second register set under the
+// MFMAs of the current one, one barrier per K = 64.
+// Measured (4096^3, one tile per CU): 860-920 TFLOP/s against the default kernel's 1140-1250 and hipBLASLt's 1400.  Ablation by K-scaling:
+// in-loop 1.9 us per slab (1.1 PFLOP/s) with ~29 us of per-tile fixed cost; fragment reads alone 1.2 us per slab, DMA + reads 1.65 us --
+// each of the three streams (DMA, ds_read, MFMA) alone takes most of a slab's time and they overlap poorly with a single wave per SIMD.
+// Kept as a correct, tested variant and as the starting point for a hand-scheduled (assembly-level) version; not selected by default.
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(const GemmArgs a) {
+    constexpr int ES = 2, TMB = 256, TNB = 256;
+    constexpr int STAGE = (TMB + TNB) * CHUNKS;       // uint4 per stage: 512 rows x 128 B = 64 KiB
+    extern __shared__ uint4 plds[];
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    if (a.group_m > 0) {
+        const int per_group = a.group_m * a.nbn;
+        const int gid = vid / per_group, first_m = gid * a.group_m;
+        const int gsz = a.nbm - first_m < a.group_m ? a.nbm - first_m : a.group_m;
+        const int loc = vid - gid * per_group;
+        tile_m = first_m + loc % gsz;
+        tile_n = loc / gsz;
+    }
+    const long long m0 = (long long)tile_m * TMB, n0 = (long long)tile_n * TNB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const long long grp = blockIdx.y;
+    const char* Xg = a.X + grp * a.a_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const long long cshift = grp * a.c_gstride;
+    // one DMA = 8 rows x 128 B; wave w stages row blocks w, w+4, ..., w+28 of X and of W (8 + 8 instructions per slab)
+    const int rl = lane >> 3, pos = lane & 7;
+    const int sck = (pos ^ rl) * 8;                   // source k offset (elements): LDS position p of row r holds chunk p ^ (r & 7)
+    const char* xsrc[8]; const char* wsrc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        long long m = m0 + 8 * (wave + 4 * i) + rl; if (m > a.M - 1) m = a.M - 1;
+        long long n = n0 + 8 * (wave + 4 * i) + rl; if (n > a.N - 1) n = a.N - 1;
+        xsrc[i] = Xg + row_off(a.xmap, m) * ES;
+        wsrc[i] = Wg + n * a.ldw * ES;
+    }
+    const int nslab = (int)(a.K / 64);
+    // K segments (implicit-GEMM taps) are whole slabs here (seg_len % 64 == 0, checked by the launcher): one scalar mapping per slab
+    const int seg_slabs = a.nseg > 1 ? (int)(a.seg_len / 64) : nslab + 1;
+    auto xk = [&](int sl) -> long long {
+        const int sg = sl / seg_slabs;
+        return ((long long)sg * a.seg_stride + (long long)(sl - sg * seg_slabs) * 64 + sck) * ES;
+    };
+    // acc[ch][rg][i][j]: column half ch (64 columns), row group rg (32 rows), then the [4 column blocks][2 row blocks] chunk the epilogue takes
+    f32x4 acc[2][4][4][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[c][r][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][r][i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)plds;
+    // fragment (row r, half kb): byte r*128 + (((kb*4 + fq) ^ (r & 7)) << 4); blocks of 16 rows are 2 KiB apart
+    const unsigned xrow = (unsigned)((wm * 128 + fr) * 128), wrow = (unsigned)(TMB * 128 + (wn * 128 + fr) * 128);
+    const unsigned sw0 = (unsigned)((fq ^ (fr & 7)) << 4), sw1 = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
+    const unsigned x0 = xrow + sw0, x1 = xrow + sw1, w0 = wrow + sw0, w1 = wrow + sw1;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+        if (sl < nslab) {
+            const long long kx = xk(sl), kw = ((long long)sl * 64 + sck) * ES;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx), (lds_void*)&plds[sl * STAGE + (wave + 4 * i) * 64], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + kw), (lds_void*)&plds[sl * STAGE + TMB * CHUNKS + (wave + 4 * i) * 64], 16, 0, 0);
+            }
+        }
+    u32x4 xa[8], wa[8], xb[8], wb[8];
+    if (nslab > 1) wait_vm_then_barrier<16>(); else wait_vm_then_barrier<0>();     // slab 0 landed for everyone
+    read_frags<8>(xa, lds0 + x0); read_frags<8>(wa, lds0 + w0);
+    const bool domfma = !(a.dbg & 2), nodma = a.dbg & 1, noread = a.dbg & 4;       // ablation switches (timing experiments only)
+    // 64 MFMAs in 16 groups of 4; before group G one fragment read (RD) and one DMA (FILL) are issued
+#define OCC_W4_GROUP(G, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL)                                                                        \
+        if (RD) { if ((G) < 8) XN[(G) & 7] = ds_read128<((G) & 7) * 2048>((RB) + (RXO)); else WN[(G) & 7] = ds_read128<((G) & 7) * 2048>((RB) + (RWO)); } \
+        if (FILL) {                                                                                                                    \
+            if ((G) < 8) __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[(G) & 7] + kxf), (lds_void*)&plds[buf * STAGE + (wave + 4 * ((G) & 7)) * 64], 16, 0, 0); \
+            else __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[(G) & 7] + kwf), (lds_void*)&plds[buf * STAGE + TMB * CHUNKS + (wave + 4 * ((G) & 7)) * 64], 16, 0, 0); \
+        }                                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+        if (domfma) _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                    \
+            const int id = (G) * 4 + t, ii = id & 7, jj = id >> 3;                                                                     \
+            acc[ii >> 2][jj >> 1][ii & 3][jj & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WC[ii]), __builtin_bit_cast(bf16x8, XC[jj]), acc[ii >> 2][jj >> 1][ii & 3][jj & 1], 0, 0, 0); \
+        }                                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);
+#define OCC_W4_HALF(XC, WC, XN, WN, RD, RB, RXO, RWO, FILL)                                                                            \
+        OCC_W4_GROUP(0, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL) OCC_W4_GROUP(1, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL)                \
+        OCC_W4_GROUP(2, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL) OCC_W4_GROUP(3, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL)                \
+        OCC_W4_GROUP(4, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL) OCC_W4_GROUP(5, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL)                \
+        OCC_W4_GROUP(6, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL) OCC_W4_GROUP(7, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL)                \
+        OCC_W4_GROUP(8, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL) OCC_W4_GROUP(9, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL)                \
+        OCC_W4_GROUP(10, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL) OCC_W4_GROUP(11, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL)              \
+        OCC_W4_GROUP(12, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL) OCC_W4_GROUP(13, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL)              \
+        OCC_W4_GROUP(14, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL) OCC_W4_GROUP(15, XC, WC, XN, WN, RD, RB, RXO, RWO, FILL)
+    int buf = 0;
+    for (int sl = 0; sl < nslab; ++sl) {
+        const unsigned cb = lds0 + (unsigned)buf * (STAGE * 16), ob = lds0 + (unsigned)(buf ^ 1) * (STAGE * 16);
+        long long kxf = 0, kwf = 0;
+        // first half: (xa, wa) hold k 0..31 of this slab; read k 32..63 of the same stage into (xb, wb)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            const bool rd = !noread;
+            OCC_W4_HALF(xa, wa, xb, wb, rd, cb, x1, w1, false)
+        }
+        // second half: every wave has read this stage (their lgkmcnt(0) above precedes the barrier) and slab sl+1 has landed
+        wait_vm_then_barrier<0>();
+        {
+            const bool rd = sl + 1 < nslab && !noread, fill = sl + 2 < nslab && !nodma;
+            if (fill) { kxf = xk(sl + 2); kwf = ((long long)(sl + 2) * 64 + sck) * ES; }
+            OCC_W4_HALF(xb, wb, xa, wa, rd, ob, x0, w0, fill)
+        }
+        buf ^= 1;
+    }
+#undef OCC_W4_HALF
+#undef OCC_W4_GROUP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // small chunks keep the epilogue's live registers low (256 accumulators leave little room; one 4x8-block call spilled)
+#define OCC_W4_EPI(CH, RG) gemm_epilogue<2>(a, acc[CH][RG], m0 + wm * 128 + (RG) * 32, n0 + wn * 128 + (CH) * 64, fr, fq, cshift);
+    OCC_W4_EPI(0, 0) OCC_W4_EPI(0, 1) OCC_W4_EPI(0, 2) OCC_W4_EPI(0, 3) OCC_W4_EPI(1, 0) OCC_W4_EPI(1, 1) OCC_W4_EPI(1, 2) OCC_W4_EPI(1, 3)
+#undef OCC_W4_EPI
+}
+
+int launch_w4(GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_t s) {
+    if (a.nseg > 1 && a.seg_len % 64 != 0) return -100;          // K segments must be whole slabs: fall back to the default kernel
+    a.nbm = (int)occ_cdiv(d->M, 256); a.nbn = (int)occ_cdiv(d->N, 256);
+    a.group_m = a.nbn >= 8 ? 4 : 0;
+    const size_t shm = (size_t)2 * 512 * CHUNKS * sizeof(uint4);
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) { occ_set_error("occ_gemm: cannot raise the LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+        raised = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_w4_kernel, dim3((unsigned)((long long)a.nbm * a.nbn), (unsigned)ng), dim3(256), shm, s, a);
+    return OCC_OK;
+}
+
+
 int gemm_family_launch(int variant, GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_t s) {
+    if (variant == 17) return launch_w4(a, d, ng, s);
     if (variant == 15 || variant == 16) return variant == 15 ? launch_ms32<2, 4, 8, 4>(a, d, ng, s) : launch_ms32<4, 2, 4, 5>(a, d, ng, s);
     if (variant == 13) {
         a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);

@@ -42,6 +42,18 @@ for name, M, N, K, gelu in shapes:
             e1.record(); torch.cuda.synchronize()
             best[v].append(e0.elapsed_time(e1) / n)
     line = "%-6s M=%6d N=%5d K=%5d " % (name, M, N, K)
+    if os.environ.get("GEMM_VENDOR"):                  # yardstick only: torch's bf16 addmm (hipBLASLt) on the same operands, no GELU
+        bb = b.bfloat16(); wt = w.t()
+        vt = []
+        for r in range(rounds + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                torch.addmm(bb, x, wt, out=out)
+            e1.record(); torch.cuda.synchronize()
+            vt.append(e0.elapsed_time(e1) / n)
+        vt = sorted(vt[1:])
+        line += " | vendor %7.1f us %6.0f TF" % (vt[len(vt) // 2] * 1e3, 2 * M * N * K / vt[len(vt) // 2] / 1e9)
     for v in variants:
         t = sorted(best[v]); med = t[len(t) // 2]
         line += " | v%d %7.1f us %6.0f TF (min %6.0f) err %.2g" % (v, med * 1e3, 2 * M * N * K / med / 1e9, 2 * M * N * K / t[0] / 1e9, err[v])
