@@ -105,55 +105,89 @@ int launch_layernorm(const void* x, void* y, const float* gamma, const float* be
 constexpr int C0_FRAMES = 256;     // frames per workgroup (64 per wave)
 constexpr int C0_MAXK = 16;
 
-template <typename TO>
+// sums of NF independent values over the wave, the NF chains interleaved so their latencies overlap
+template <int NF> __device__ __forceinline__ void wave_sum_multi(float (&v)[NF]) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) v[u] += occ_dpp<0xB1>(v[u]);
+#pragma unroll
+    for (int u = 0; u < NF; ++u) v[u] += occ_dpp<0x4E>(v[u]);
+#pragma unroll
+    for (int u = 0; u < NF; ++u) v[u] += occ_dpp<0x141>(v[u]);
+#pragma unroll
+    for (int u = 0; u < NF; ++u) v[u] += occ_dpp<0x140>(v[u]);
+#pragma unroll
+    for (int u = 0; u < NF; ++u) v[u] += __shfl_xor(v[u], 16, 64);
+#pragma unroll
+    for (int u = 0; u < NF; ++u) v[u] += __shfl_xor(v[u], 32, 64);
+}
+
+// KT = compile-time tap count (10 for wav2vec2, 16 = generic with zero-padded taps): no per-tap branches, the frame's samples are
+// fetched as one batch of LDS broadcasts; C0_NF frames are in flight per wave so the two cross-lane reductions of a frame overlap
+// with those of its neighbours (the loop is VALU/latency bound: ~330 instructions per frame before, 2 serial reductions each).
+constexpr int C0_NF = 4;
+template <typename TO, int KT>
 __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ wav, const float* __restrict__ w, const float* __restrict__ bias,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, TO* __restrict__ out,
                                                            int L, int Tout, int k, int stride, float eps) {
     extern __shared__ __attribute__((aligned(16))) float smp[];
     const int b = blockIdx.y, f0 = blockIdx.x * C0_FRAMES;
-    const int nsamp = (C0_FRAMES - 1) * stride + k;
+    const int nsamp = (C0_FRAMES - 1) * stride + KT;
     const float* wb = wav + (size_t)b * L;
     for (int i = threadIdx.x; i < nsamp; i += 256) {
         const int g = f0 * stride + i;
         smp[i] = g < L ? wb[g] : 0.f;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = lane * 8;
-    float wr[8][C0_MAXK], br[8], gr[8], ber[8];
+    float wr[8][KT], br[8], gr[8], ber[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         br[e] = bias[c0 + e]; gr[e] = gamma[c0 + e]; ber[e] = beta[c0 + e];
 #pragma unroll
-        for (int t = 0; t < C0_MAXK; ++t) wr[e][t] = t < k ? w[(size_t)(c0 + e) * k + t] : 0.f;
+        for (int t = 0; t < KT; ++t) wr[e][t] = t < k ? w[(size_t)(c0 + e) * k + t] : 0.f;
     }
     __syncthreads();
-    for (int fi = 0; fi < C0_FRAMES / 4; ++fi) {
-        const int fl = wave * (C0_FRAMES / 4) + fi;
+    constexpr int FPW = C0_FRAMES / 4;
+    for (int fi = 0; fi < FPW; fi += C0_NF) {
+        const int fl = wave * FPW + fi;
         const int f = f0 + fl;
         if (f >= Tout) break;
-        float acc[8];
+        float acc[C0_NF][8], sm[C0_NF], q[C0_NF];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = br[e];
+        for (int u = 0; u < C0_NF; ++u) {
+            float xv[KT];
 #pragma unroll
-        for (int t = 0; t < C0_MAXK; ++t) {
-            if (t < k) {
-                const float xv = smp[fl * stride + t];
+            for (int t = 0; t < KT; ++t) xv[t] = smp[(fl + u) * stride + t];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(wr[e][t], xv, acc[e]);
-            }
+            for (int e = 0; e < 8; ++e) acc[u][e] = br[e];
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[u][e] = fmaf(wr[e][t], xv[t], acc[u][e]);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += acc[u][e];
+            sm[u] = s;
         }
-        float s = 0.f;
+        wave_sum_multi<C0_NF>(sm);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += acc[e];
-        const float mean = wave_sum(s) * (1.0f / 512.0f);
-        float q = 0.f;
+        for (int u = 0; u < C0_NF; ++u) {
+            sm[u] *= (1.0f / 512.0f);
+            float qq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = acc[e] - mean; q += d * d; }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 512.0f) + eps);
-        float o[8];
+            for (int e = 0; e < 8; ++e) { const float d = acc[u][e] - sm[u]; qq += d * d; }
+            q[u] = qq;
+        }
+        wave_sum_multi<C0_NF>(q);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = gelu_erf((acc[e] - mean) * rstd * gr[e] + ber[e]);
-        Vec8<TO>::store(out + ((size_t)b * Tout + f) * 512 + c0, o);
+        for (int u = 0; u < C0_NF; ++u) {
+            if (f + u >= Tout) break;
+            const float rstd = 1.0f / sqrtf(q[u] * (1.0f / 512.0f) + eps);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gelu_erf((acc[u][e] - sm[u]) * rstd * gr[e] + ber[e]);
+            Vec8<TO>::store(out + ((size_t)b * Tout + f + u) * 512 + c0, o);
+        }
     }
 }
 
@@ -517,13 +551,14 @@ int occ_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const
     OCC_CHECK_ARG(k >= 1 && k <= C0_MAXK && stride >= 1 && stride <= 16, "occ_conv0_ln_gelu: k in [1,16], stride in [1,16]");
     OCC_CHECK_ARG(B >= 1 && B < 65536 && L >= k && Tout == (L - k) / stride + 1, "occ_conv0_ln_gelu: Tout must equal (L-k)/stride+1");
     const dim3 grid((unsigned)occ_cdiv(Tout, C0_FRAMES), (unsigned)B), block(256);
-    const size_t shm = ((C0_FRAMES - 1) * stride + k) * sizeof(float);
+    const int kt = k <= 10 ? 10 : C0_MAXK;
+    const size_t shm = ((C0_FRAMES - 1) * stride + kt) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    if (out_dtype == OCC_F32)
-        hipLaunchKernelGGL(conv0_ln_gelu_kernel<float>, grid, block, shm, s, wav, w, bias, gamma, beta, (float*)out, (int)L, (int)Tout, (int)k, (int)stride, eps);
-    else if (out_dtype == OCC_BF16)
-        hipLaunchKernelGGL(conv0_ln_gelu_kernel<unsigned short>, grid, block, shm, s, wav, w, bias, gamma, beta, (unsigned short*)out, (int)L, (int)Tout, (int)k, (int)stride, eps);
+#define OCC_C0_LAUNCH(TO, KT) hipLaunchKernelGGL((conv0_ln_gelu_kernel<TO, KT>), grid, block, shm, s, wav, w, bias, gamma, beta, (TO*)out, (int)L, (int)Tout, (int)k, (int)stride, eps)
+    if (out_dtype == OCC_F32) { if (kt == 10) OCC_C0_LAUNCH(float, 10); else OCC_C0_LAUNCH(float, C0_MAXK); }
+    else if (out_dtype == OCC_BF16) { if (kt == 10) OCC_C0_LAUNCH(unsigned short, 10); else OCC_C0_LAUNCH(unsigned short, C0_MAXK); }
     else { occ_set_error("occ_conv0_ln_gelu: out dtype must be f32 or bf16"); return OCC_EUNSUPPORTED; }
+#undef OCC_C0_LAUNCH
     OCC_LAUNCH_CHECK("occ_conv0_ln_gelu");
     return OCC_OK;
 }

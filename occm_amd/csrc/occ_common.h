@@ -51,6 +51,17 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// f32: the four steps inside a 16-lane row go through DPP (quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror, row_mirror:
+// VALU operand modifiers, no LDS crossbar round trip), only the two cross-row steps use ds_bpermute.  Every step pairs lanes
+// symmetrically, so all 64 lanes still end with the bit-identical sum.
+template <int CTRL> __device__ __forceinline__ float occ_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <> __device__ __forceinline__ float wave_sum<float>(float v) {
+    v += occ_dpp<0xB1>(v); v += occ_dpp<0x4E>(v); v += occ_dpp<0x141>(v); v += occ_dpp<0x140>(v);
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
 template <typename T> __device__ __forceinline__ T wave_max(T v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { T u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
