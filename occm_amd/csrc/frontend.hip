@@ -516,6 +516,142 @@ __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned
     }
 }
 
+// Whole head on chip, V row-major (the fragment scheme of the kernel above, the V handling of the streaming kernel): one workgroup
+// per (batch, head) stages K (swizzled 128-byte rows) and V ([key][d], 160-byte rows, fragments by ds_read_b64_tr_b16) ONCE for all
+// NP*32 >= T keys, then its four waves walk the 16-query blocks with a single-pass softmax; the next block's Q rows are fetched under
+// the current block's arithmetic.  At T = 199 (NP = 7) the streaming kernel staged every head four times (once per 64 queries) and
+// ran two key blocks of 128 with 22 % padding.  LDS 28 + 35 KiB: two workgroups per CU.
+template <int NP>
+__global__ __launch_bounds__(256, 2) void attention_mfma_head_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
+                                                                    int Tn, int H, long long ld_qkv, long long ld_out, float scale, float* __restrict__ lse) {
+    constexpr int NK = NP * 32, VROW = 160;
+    __shared__ uint4 Ks[NK * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[NK * VROW];
+    const int D = H * 64;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int qchunk = (((Tn + 15) / 16 + gridDim.y - 1) / gridDim.y) * 16;
+    const int q_begin = blockIdx.y * qchunk, q_end = q_begin + qchunk < Tn ? q_begin + qchunk : Tn;
+    const unsigned short* base = qkv + (size_t)b * Tn * ld_qkv + (size_t)h * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    int q0 = q_begin + wave * 16;
+    uint4 qf[2];
+    {
+        const int qr = q0 + fr < Tn ? q0 + fr : Tn - 1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[s] = *reinterpret_cast<const uint4*>(base + (size_t)qr * ld_qkv + s * 32 + g * 8);
+    }
+    {   // all 2*NP loads of this thread are issued before the first LDS write: one exposed memory latency
+        uint4 kv[NP], vv[NP];
+        const int ch = threadIdx.x & 7;
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int key = it * 32 + (threadIdx.x >> 3);
+            const int kc = key < Tn ? key : Tn - 1;
+            kv[it] = *reinterpret_cast<const uint4*>(base + (size_t)kc * ld_qkv + D + ch * 8);
+            vv[it] = *reinterpret_cast<const uint4*>(base + (size_t)kc * ld_qkv + 2 * D + ch * 8);
+            if (key >= Tn) { kv[it] = make_uint4(0, 0, 0, 0); vv[it] = kv[it]; }
+        }
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int key = it * 32 + (threadIdx.x >> 3);
+            Ks[key * 8 + (ch ^ (key & 7))] = kv[it];
+            *reinterpret_cast<uint4*>(Vs + key * VROW + ch * 16) = vv[it];
+        }
+    }
+    __syncthreads();
+    const float c = scale * 1.44269504088896340736f;
+    for (; q0 < q_end; q0 += 64) {                         // wave-uniform bounds: EXEC stays full for the transposing reads
+        const int qrow = q0 + fr;
+        uint4 qn[2] = {qf[0], qf[1]};
+        if (q0 + 64 < q_end) {
+            const int qr = q0 + 64 + fr < Tn ? q0 + 64 + fr : Tn - 1;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) qn[s] = *reinterpret_cast<const uint4*>(base + (size_t)qr * ld_qkv + s * 32 + g * 8);
+        }
+        af32x4 sc[2 * NP];
+#pragma unroll
+        for (int t = 0; t < 2 * NP; ++t) {
+            sc[t] = (af32x4){0.f, 0.f, 0.f, 0.f};
+            const int kr = t * 16 + fr;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 kf = Ks[kr * 8 + ((s * 4 + g) ^ (kr & 7))];
+                sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<abf16x8*>(&kf), *reinterpret_cast<abf16x8*>(&qf[s]), sc[t], 0, 0, 0);
+            }
+        }
+        // softmax on the raw scores: p = exp2(c*s - c*max) is one FMA + one v_exp per element (c > 0, so the max commutes with the scale);
+        // only the last tiles can hold padded keys, and which ones is wave-uniform
+        const int t_pad = Tn >> 4;                         // first 16-key tile that may contain keys >= Tn
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < 2 * NP; ++t) {
+            if (t >= t_pad) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (t * 16 + g * 4 + r >= Tn) sc[t][r] = -3.0e38f;
+            }
+            mx = fmaxf(mx, fmaxf(fmaxf(sc[t][0], sc[t][1]), fmaxf(sc[t][2], sc[t][3])));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nmc = -mx * c;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * NP; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sc[t][r], c, nmc));      // masked: -3e38*c + nmc -> exp2 = 0
+                sc[t][r] = pv;
+                sum += pv;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        if (lse && g == 0 && qrow < Tn) lse[(size_t)bh * Tn + qrow] = mx * c + __builtin_amdgcn_logf(sum);
+        af32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = (af32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            unsigned pw[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                pw[e] = (unsigned)f32_to_bf16_bits(sc[2 * u][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u][2 * e + 1]) << 16);
+                pw[2 + e] = (unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e + 1]) << 16);
+            }
+            uint4 pf = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const unsigned char* vr = Vs + (u * 32 + 4 * g + (fr >> 2)) * VROW + (dt * 16 + (fr & 3) * 4) * 2;
+                const att_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s16x4*)vr);
+                const att_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s16x4*)(vr + 16 * VROW));
+                const abf16x8 vf = __builtin_bit_cast(abf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<abf16x8*>(&pf), vf, oacc[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ql = g * 4 + r;
+            const float iv = __shfl(inv, ql, 64);
+            const int q = q0 + ql;
+            if (q < Tn) {
+                unsigned short* orow = out + ((size_t)b * Tn + q) * ld_out + (size_t)h * 64 + fr;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) orow[dt * 16] = f32_to_bf16_bits(oacc[dt][r] * iv);
+            }
+        }
+        qf[0] = qn[0]; qf[1] = qn[1];
+    }
+}
+
+template <int NP>
+void launch_attention_head(const void* qkv, void* out, int B, int T, int H, long long ld_qkv, long long ld_out, float scale, float* lse, hipStream_t s) {
+    int ysplit = 1;
+    while ((long long)B * H * ysplit < 512 && ysplit * 64 < T) ysplit *= 2;
+    hipLaunchKernelGGL(attention_mfma_head_kernel<NP>, dim3((unsigned)(B * H), (unsigned)ysplit), dim3(256), 0, s, (const unsigned short*)qkv, (unsigned short*)out, T, H,
+                       ld_qkv, ld_out, scale, lse);
+}
+
 template <int NP>
 void launch_attention_mfma(const void* qkv, void* out, int B, int T, int H, long long ld_qkv, long long ld_out, float scale, float* lse, hipStream_t s) {
     // one workgroup per head when there are enough heads to fill the chip (2 workgroups per CU fit), else split the queries
@@ -580,6 +716,15 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
         else if (np <= 7) launch_attention_mfma<7>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
         else launch_attention_mfma<8>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
         OCC_LAUNCH_CHECK("occ_attention(mfma)");
+        return OCC_OK;
+    }
+    static const int att_head = getenv("OCC_ATT_HEAD") ? atoi(getenv("OCC_ATT_HEAD")) : 1;
+    if (att_head && dtype == OCC_BF16 && hd == 64 && T > 128 && T <= 224 && ld_qkv % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) {
+        // 128 < T <= 224 (the 4 s training utterances: T = 199): whole head on chip, staged once
+        if (T <= 160) launch_attention_head<5>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
+        else if (T <= 192) launch_attention_head<6>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
+        else launch_attention_head<7>(qkv, out, (int)B, (int)T, (int)H, ld_qkv, ld_out, scale, lse, s);
+        OCC_LAUNCH_CHECK("occ_attention(mfma, head)");
         return OCC_OK;
     }
     if (dtype == OCC_BF16 && (hd == 64 || hd == 80) && ld_qkv % 8 == 0 && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) {   // any T: keys streamed in blocks

@@ -118,7 +118,8 @@ def test_conv0_ln_gelu(L):
     torch.testing.assert_close(outb.cpu().float(), ref, rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("B,T,H,hd", [(2, 199, 16, 64), (1, 7, 2, 64), (3, 65, 4, 80), (2, 201, 4, 16), (2, 201, 3, 64), (1, 64, 2, 64), (2, 256, 2, 64), (1, 100, 5, 64), (1, 290, 2, 64)])
+@pytest.mark.parametrize("B,T,H,hd", [(2, 199, 16, 64), (1, 7, 2, 64), (3, 65, 4, 80), (2, 201, 4, 16), (2, 201, 3, 64), (1, 64, 2, 64), (2, 256, 2, 64), (1, 100, 5, 64), (1, 290, 2, 64),
+                                        (2, 150, 3, 64), (2, 161, 2, 64), (2, 192, 3, 64), (40, 199, 16, 64), (1, 224, 2, 64), (1, 225, 2, 64)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_attention(B, T, H, hd, dt):
     from occm_amd import ops
