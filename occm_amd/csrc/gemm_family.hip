@@ -101,6 +101,26 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void gemm_bf16_ms_kernel(const G
         // Fragment reads are inline asm on purpose: hipcc treats an LDS-DMA as a pending LDS store and would put
         // `s_waitcnt vmcnt(0)` in front of any ds_read it can see, draining the slabs that are meant to stay in flight.
         const unsigned sb = lds0 + (unsigned)buf * (STAGE * 16);
+        if constexpr (WGM * WGN == 16) {
+            // 16 waves = 4 per SIMD = 128 registers each: one fragment set, refilled for the second half-slab (the other three waves
+            // of the SIMD cover the read latency)
+            u32x4 wq[4], xq[NJ];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                read_frags<4>(wq, sb + (kb ? (woff0 ^ 64) : woff0)); read_frags<NJ>(xq, sb + (kb ? (xoff0 ^ 64) : xoff0));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[i]), __builtin_bit_cast(bf16x8, xq[j]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            buf = buf + 1 == NST ? 0 : buf + 1;
+            nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+            continue;
+        }
         u32x4 wf[2][4], xf[2][NJ];
         if (!(a.dbg & 4)) {
             read_frags<4>(wf[0], sb + woff0); read_frags<NJ>(xf[0], sb + xoff0);
@@ -744,6 +764,7 @@ int launch_w4(GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_t s) 
 
 int gemm_family_launch(int variant, GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_t s) {
     if (variant == 17) return launch_w4(a, d, ng, s);
+    if (variant == 20) return launch_ms<4, 4, 4, 2>(a, d, ng, s);          // 16 waves of 64x64 on a 256x256 tile, double-buffered
     if (variant == 15 || variant == 16) return variant == 15 ? launch_ms32<2, 4, 8, 4>(a, d, ng, s) : launch_ms32<4, 2, 4, 5>(a, d, ng, s);
     if (variant == 13) {
         a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
