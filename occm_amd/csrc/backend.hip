@@ -1133,7 +1133,7 @@ static int bn_chunks(int64_t rows, int64_t C, long long* rpc) {
     long long nchunk = occ_cdiv(rows, 64);
     const long long cap = C % 4 == 0 ? (512 * 256) / C : 512;
     if (nchunk > cap) nchunk = cap;
-    if (nchunk > 2048) nchunk = 2048;
+    if (nchunk > 512) nchunk = 512;             // two workgroups per CU feed the partial kernel; the finalize wave walks nchunk / 64 strided rows (10 us at 1386)
     *rpc = occ_cdiv(rows, nchunk);
     return (int)occ_cdiv(rows, *rpc);
 }
