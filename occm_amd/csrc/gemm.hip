@@ -191,9 +191,11 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
         tile_m = first_m + loc % gsz;
         tile_n = loc / gsz;
     }
-    const long long m0 = (long long)tile_m * TMT, n0 = (long long)tile_n * TN;
+    const int trows = TMT == 128 ? a.tile_rows : TMT;        // rows this tile owns (<= TMT); rows beyond belong to the next tile
+    const long long m0 = (long long)tile_m * trows, n0 = (long long)tile_n * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = TMT == 128 ? (wave & 1) : (wave & 3), wn = TMT == 128 ? (wave >> 1) : (wave >> 2);
+    const int njv = trows - wm * 64 >= 64 ? 4 : (trows - wm * 64 <= 0 ? 0 : (trows - wm * 64) >> 4);   // 16-row blocks of this wave inside the tile
     const long long grp = blockIdx.y;
     const char* Xg = a.X + grp * a.a_gstride * ES;
     const char* Wg = a.W + grp * a.w_gstride * ES;
@@ -252,17 +254,30 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
                 const int rx = wm * 64 + i * 16 + fr;
                 xf[i] = ldsX[rx * CHUNKS + (chk ^ (rx & 7))];
             }
+            if (TMT != 128 || njv == 4) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+            } else {                                       // short tile: this wave owns fewer than four row blocks (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < njv) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         __syncthreads();
     }
-    if constexpr (SPLITK) gemm_epilogue_atomic<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
-    else gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+    GemmArgs ae = a;                                       // the epilogue stores rows below M only: cap it at the end of this tile
+    if (TMT == 128 && m0 + trows < a.M) ae.M = m0 + trows;
+    if constexpr (SPLITK) gemm_epilogue_atomic<4>(ae, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+    else gemm_epilogue<4>(ae, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -380,9 +395,11 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_hs_kernel(const GemmArgs a) 
         tile_m = first_m + loc % gsz;
         tile_n = loc / gsz;
     }
-    const long long m0 = (long long)tile_m * TMT, n0 = (long long)tile_n * TN;
+    const int trows = a.tile_rows;
+    const long long m0 = (long long)tile_m * trows, n0 = (long long)tile_n * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
+    const int njv = trows - wm * 64 >= 64 ? 4 : (trows - wm * 64 <= 0 ? 0 : (trows - wm * 64) >> 4);
     const long long grp = blockIdx.y;
     const char* Xg = a.X + grp * a.a_gstride * ES;
     const char* Wg = a.W + grp * a.w_gstride * ES;
@@ -433,7 +450,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_hs_kernel(const GemmArgs a) 
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory");                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                        \
-            acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[I]), __builtin_bit_cast(bf16x8, xf[j]), acc[I][j], 0, 0, 0);
+            if (j < njv) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[I]), __builtin_bit_cast(bf16x8, xf[j]), acc[I][j], 0, 0, 0);
         OCC_HS_ROW(0, 3) OCC_HS_ROW(1, 2) OCC_HS_ROW(2, 1) OCC_HS_ROW(3, 0)
 #undef OCC_HS_ROW
         if (h + 2 < nhalf) {
@@ -441,7 +458,9 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_hs_kernel(const GemmArgs a) 
             issue(h + 2);
         }
     }
-    gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+    GemmArgs ae = a;
+    if (m0 + trows < a.M) ae.M = m0 + trows;
+    gemm_epilogue<4>(ae, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -501,14 +520,31 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     a.ksplit = 1; a.slabs_per_split = 0; a.ngroups = 1;
     a.dbg = g_dbg;
     a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
+    a.tile_rows = TM;
     // grouped tile order (8 m-tiles per W panel) measured +3 % on the N >= 3072 front-end GEMMs and +10 % at 4096^3, -2 % at N = 1024
     static const int group_m_env = getenv("OCC_GEMM_GROUP_M") ? atoi(getenv("OCC_GEMM_GROUP_M")) : -1;
     a.group_m = group_m_env >= 0 ? group_m_env : (a.nbn >= 16 ? 8 : 0);
     const long long ng = d->n_groups > 1 ? d->n_groups : 1;
     a.a_gstride = ng > 1 ? d->a_group_stride : 0; a.w_gstride = ng > 1 ? d->w_group_stride : 0; a.c_gstride = ng > 1 ? d->c_group_stride : 0;
     OCC_CHECK_ARG(ng < 65536 && a.a_gstride % ce == 0 && a.w_gstride % ce == 0 && a.c_gstride % 4 == 0, "occ_gemm: bad group strides");
-    const long long total = (long long)a.nbm * a.nbn;
+    long long total = (long long)a.nbm * a.nbn;
     OCC_CHECK_ARG(total < (1ll << 30), "occ_gemm: too many tiles");
+    // Under-filled launches (at most two 128-row tiles per CU: out-proj and fc2 at M = 6368 have 400 tiles for 256 CUs, so 144 CUs do
+    // two and the rest one): shorter tiles spread the rows evenly.  Pick the height h (multiple of 16) that minimises
+    // ceil(tiles(h) / CUs) * h; the LDS image and the staging stay 128 rows, a short tile simply skips its missing row blocks.
+    static const int tile_rows_env = getenv("OCC_GEMM_TILE_ROWS") ? atoi(getenv("OCC_GEMM_TILE_ROWS")) : 0;
+    // (long-K launches of this kind go to the half-slab pipeline below, where the short tile measured 7 % slower: they keep 128 rows)
+    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && d->K / 64 < 32 && g_variant == 1 && total * ng <= 2ll * cu_count() && total * ng > cu_count() / 2) {
+        long long best_h = TM, best_cost = occ_cdiv(total * ng, cu_count()) * TM;
+        for (long long h = 112; h >= 64; h -= 16) {
+            const long long cost = occ_cdiv(occ_cdiv(d->M, h) * a.nbn * ng, cu_count()) * h;
+            if (cost < best_cost) { best_cost = cost; best_h = h; }
+        }
+        if (tile_rows_env >= 16 && tile_rows_env <= 128 && tile_rows_env % 16 == 0) best_h = tile_rows_env;
+        a.tile_rows = (int)best_h;
+        a.nbm = (int)occ_cdiv(d->M, best_h);
+        total = (long long)a.nbm * a.nbn;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int variant = g_variant;
     const long long nbm256 = occ_cdiv(d->M, 256);

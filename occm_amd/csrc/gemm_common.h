@@ -28,6 +28,7 @@ struct GemmArgs {
     int ngroups;             // persistent kernel: groups folded into the tile id
     int ksplit;              // > 1: the K range is cut into ksplit pieces handled by different workgroups, C += alpha*acc with f32 atomics
     int slabs_per_split;
+    int tile_rows;           // default 128x128 kernels: rows per output tile (multiple of 16, <= 128; the LDS image stays 128 rows) -- see occ_gemm
     int dbg;                 // ablation bits (timing experiments only, results wrong): 1 no loads in the K loop, 2 no MFMA, 4 no fragment reads
 };
 
