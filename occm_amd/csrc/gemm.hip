@@ -168,7 +168,7 @@ __global__ __launch_bounds__(THREADS, TNT == 128 ? 2 : 3) void gemm_kernel(const
 // TMT = 128: 4 waves (2x2), 32 KiB LDS, 4 workgroups per CU.  TMT = 256: 8 waves (4x2) on a 256x128 tile, 48 KiB LDS,
 // 2 workgroups per CU: the same 16 waves per CU but 25 % fewer L2->LDS bytes per FLOP (the 128x128 tile moves one byte
 // per 64 FLOP, which is about what a CU can pull from L2 at its MFMA rate).
-template <int TMT, bool SPLITK = false>
+template <int TMT, bool SPLITK = false, int TR = TMT>      // TR: rows a tile owns; 112 (with TMT = 128) is the one short height compiled
 __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma_kernel(const GemmArgs a) {
     constexpr int ES = 2, CE = 8, SLAB_K = 64;
     constexpr int NT = 2 * TMT;                 // threads
@@ -191,11 +191,11 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
         tile_m = first_m + loc % gsz;
         tile_n = loc / gsz;
     }
-    const int trows = TMT == 128 ? a.tile_rows : TMT;        // rows this tile owns (<= TMT); rows beyond belong to the next tile
+    constexpr int trows = TR;                               // rows this tile owns (<= TMT; TR < TMT = short tile, the rows beyond belong to the next tile)
     const long long m0 = (long long)tile_m * trows, n0 = (long long)tile_n * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = TMT == 128 ? (wave & 1) : (wave & 3), wn = TMT == 128 ? (wave >> 1) : (wave >> 2);
-    const int njv = trows - wm * 64 >= 64 ? 4 : (trows - wm * 64 <= 0 ? 0 : (trows - wm * 64) >> 4);   // 16-row blocks of this wave inside the tile
+    const int njv = TR == TMT || wm == 0 ? 4 : (TR - 64) / 16;   // 16-row blocks of this wave inside the tile (short tiles are 80 .. 112 rows)
     const long long grp = blockIdx.y;
     const char* Xg = a.X + grp * a.a_gstride * ES;
     const char* Wg = a.W + grp * a.w_gstride * ES;
@@ -254,30 +254,20 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
                 const int rx = wm * 64 + i * 16 + fr;
                 xf[i] = ldsX[rx * CHUNKS + (chk ^ (rx & 7))];
             }
-            if (TMT != 128 || njv == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (TR != TMT && j == 3 && njv < 4) continue;          // short tile (TR = 112): the upper waves own three row blocks (wave-uniform)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
-            } else {                                       // short tile: this wave owns fewer than four row blocks (wave-uniform)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (j < njv) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
-                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();
     }
-    GemmArgs ae = a;                                       // the epilogue stores rows below M only: cap it at the end of this tile
-    if (TMT == 128 && m0 + trows < a.M) ae.M = m0 + trows;
-    if constexpr (SPLITK) gemm_epilogue_atomic<4>(ae, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
-    else gemm_epilogue<4>(ae, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+    const long long mlim = TR == TMT ? -1 : (m0 + trows < a.M ? m0 + trows : a.M);     // short tile: stop storing at its own end
+    if constexpr (SPLITK) gemm_epilogue_atomic<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift, mlim);
+    else gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift, nullptr, mlim);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,11 +385,9 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_hs_kernel(const GemmArgs a) 
         tile_m = first_m + loc % gsz;
         tile_n = loc / gsz;
     }
-    const int trows = a.tile_rows;
-    const long long m0 = (long long)tile_m * trows, n0 = (long long)tile_n * TN;
+    const long long m0 = (long long)tile_m * TMT, n0 = (long long)tile_n * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int njv = trows - wm * 64 >= 64 ? 4 : (trows - wm * 64 <= 0 ? 0 : (trows - wm * 64) >> 4);
     const long long grp = blockIdx.y;
     const char* Xg = a.X + grp * a.a_gstride * ES;
     const char* Wg = a.W + grp * a.w_gstride * ES;
@@ -450,7 +438,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_hs_kernel(const GemmArgs a) 
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory");                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                        \
-            if (j < njv) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[I]), __builtin_bit_cast(bf16x8, xf[j]), acc[I][j], 0, 0, 0);
+            acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[I]), __builtin_bit_cast(bf16x8, xf[j]), acc[I][j], 0, 0, 0);
         OCC_HS_ROW(0, 3) OCC_HS_ROW(1, 2) OCC_HS_ROW(2, 1) OCC_HS_ROW(3, 0)
 #undef OCC_HS_ROW
         if (h + 2 < nhalf) {
@@ -458,9 +446,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_hs_kernel(const GemmArgs a) 
             issue(h + 2);
         }
     }
-    GemmArgs ae = a;
-    if (m0 + trows < a.M) ae.M = m0 + trows;
-    gemm_epilogue<4>(ae, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+    gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -527,24 +513,8 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     const long long ng = d->n_groups > 1 ? d->n_groups : 1;
     a.a_gstride = ng > 1 ? d->a_group_stride : 0; a.w_gstride = ng > 1 ? d->w_group_stride : 0; a.c_gstride = ng > 1 ? d->c_group_stride : 0;
     OCC_CHECK_ARG(ng < 65536 && a.a_gstride % ce == 0 && a.w_gstride % ce == 0 && a.c_gstride % 4 == 0, "occ_gemm: bad group strides");
-    long long total = (long long)a.nbm * a.nbn;
+    const long long total = (long long)a.nbm * a.nbn;
     OCC_CHECK_ARG(total < (1ll << 30), "occ_gemm: too many tiles");
-    // Under-filled launches (at most two 128-row tiles per CU: out-proj and fc2 at M = 6368 have 400 tiles for 256 CUs, so 144 CUs do
-    // two and the rest one): shorter tiles spread the rows evenly.  Pick the height h (multiple of 16) that minimises
-    // ceil(tiles(h) / CUs) * h; the LDS image and the staging stay 128 rows, a short tile simply skips its missing row blocks.
-    static const int tile_rows_env = getenv("OCC_GEMM_TILE_ROWS") ? atoi(getenv("OCC_GEMM_TILE_ROWS")) : 0;
-    // (long-K launches of this kind go to the half-slab pipeline below, where the short tile measured 7 % slower: they keep 128 rows)
-    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && d->K / 64 < 32 && g_variant == 1 && total * ng <= 2ll * cu_count() && total * ng > cu_count() / 2) {
-        long long best_h = TM, best_cost = occ_cdiv(total * ng, cu_count()) * TM;
-        for (long long h = 112; h >= 64; h -= 16) {
-            const long long cost = occ_cdiv(occ_cdiv(d->M, h) * a.nbn * ng, cu_count()) * h;
-            if (cost < best_cost) { best_cost = cost; best_h = h; }
-        }
-        if (tile_rows_env >= 16 && tile_rows_env <= 128 && tile_rows_env % 16 == 0) best_h = tile_rows_env;
-        a.tile_rows = (int)best_h;
-        a.nbm = (int)occ_cdiv(d->M, best_h);
-        total = (long long)a.nbm * a.nbn;
-    }
     hipStream_t s = (hipStream_t)stream;
     const int variant = g_variant;
     const long long nbm256 = occ_cdiv(d->M, 256);
@@ -592,7 +562,19 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
             a.R = nullptr;
             hipLaunchKernelGGL((gemm_bf16_dma_kernel<128, true>), dim3((unsigned)(total * a.ksplit), (unsigned)ng), dim3(THREADS), 0, s, a);
         } else
-            hipLaunchKernelGGL(gemm_bf16_dma_kernel<128>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+        {
+            // Experiment switch (OCC_GEMM_TILE_ROWS=112): 112-row tiles on the same 128-row LDS image, meant to spread M = 6368 more evenly
+            // over the CUs (out-proj: 400 tiles of 128 rows for 256 CUs).  Measured 5-15 % SLOWER than 128 rows on every front-end shape
+            // (out-proj 27.6 vs 25.5 us, fc1 83 vs 72 us), so it is never selected automatically.
+            static const int tile_rows_env = getenv("OCC_GEMM_TILE_ROWS") ? atoi(getenv("OCC_GEMM_TILE_ROWS")) : 0;
+            const bool use112 = tile_rows_env == 112;
+            if (use112) {
+                a.tile_rows = 112;
+                a.nbm = (int)occ_cdiv(d->M, 112);
+                hipLaunchKernelGGL((gemm_bf16_dma_kernel<128, false, 112>), dim3((unsigned)((long long)a.nbm * a.nbn), (unsigned)ng), dim3(THREADS), 0, s, a);
+            } else
+                hipLaunchKernelGGL(gemm_bf16_dma_kernel<128>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+        }
     }
     else if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<1>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else if (d->ab_dtype == OCC_F32_AS_BF16 && d->N <= 64 && g_variant != 14) {        // narrow outputs: 128x64 tile

@@ -49,7 +49,7 @@ __device__ __forceinline__ float act_rt(int act, float v) {
 // round reaching it together) was a third of a K = 1024 GEMM's run time.
 template <int NJ, bool HASB, bool GELU, bool HASR, bool CBF>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
-                                                   const f32x4* breg) {
+                                                   const f32x4* breg, long long mlim) {
     f32x4 bv[4];
     if (HASB) {
 #pragma unroll
@@ -62,7 +62,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const long long m = mrow0 + j * 16 + fr;
-        if (m >= a.M) continue;
+        if (m >= mlim) continue;
         const long long coff = row_off(a.cmap, m) + cshift;
         const long long roff = HASR ? row_off(a.rmap, m) + cshift : 0;
 #pragma unroll
@@ -88,11 +88,13 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
 // Split-K epilogue: C (f32) += alpha * acc with float atomics; used for weight-gradient GEMMs whose output has only a few dozen
 // tiles while K is the whole batch (the caller passes R == C, i.e. "accumulate"; the pieces add onto what C holds).
 template <int NJ>
-__device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift) {
+__device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
+                                                     long long mlim_in = -1) {
+    const long long mlim = mlim_in >= 0 ? mlim_in : a.M;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const long long m = mrow0 + j * 16 + fr;
-        if (m >= a.M) continue;
+        if (m >= mlim) continue;
         float* crow = reinterpret_cast<float*>(a.C) + row_off(a.cmap, m) + cshift;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -108,11 +110,12 @@ __device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& a, f32x4 (&
 // mrow0 / ncol0 = first row / column of the wave's sub-tile.  A lane owns C[m][n..n+3].
 template <int NJ>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
-                                              const f32x4* breg = nullptr) {
+                                              const f32x4* breg = nullptr, long long mlim_in = -1) {
+    const long long mlim = mlim_in >= 0 ? mlim_in : a.M;        // rows this call may store: a short tile stops at its own end
     if (a.alpha == 1.0f && !a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU) && (!a.R || a.r_dtype == OCC_F32)) {
         // wave-uniform flags -> one scalar branch chain into a straight-line instantiation
         const int key = (a.bias ? 8 : 0) | (a.act == OCC_ACT_GELU ? 4 : 0) | (a.R ? 2 : 0) | (a.c_dtype != OCC_F32 ? 1 : 0);
-#define OCC_EPI(K, B, G, R, C) case K: gemm_epilogue_fast<NJ, B, G, R, C>(a, acc, mrow0, ncol0, fr, fq, cshift, breg); break;
+#define OCC_EPI(K, B, G, R, C) case K: gemm_epilogue_fast<NJ, B, G, R, C>(a, acc, mrow0, ncol0, fr, fq, cshift, breg, mlim); break;
         switch (key) {
             OCC_EPI(0, false, false, false, false) OCC_EPI(1, false, false, false, true) OCC_EPI(2, false, false, true, false) OCC_EPI(3, false, false, true, true)
             OCC_EPI(4, false, true, false, false) OCC_EPI(5, false, true, false, true) OCC_EPI(6, false, true, true, false) OCC_EPI(7, false, true, true, true)
@@ -125,7 +128,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const long long m = mrow0 + j * 16 + fr;
-        if (m >= a.M) continue;
+        if (m >= mlim) continue;
         const long long coff = row_off(a.cmap, m) + cshift;
         const long long roff = a.R ? row_off(a.rmap, m) + cshift : 0;
 #pragma unroll

@@ -33,3 +33,35 @@ def test_host_argument_validation_needs_no_gpu():
     assert rc == -1 and b"null pointer" in handle.occ_last_error()
     with pytest.raises(_lib.OccError):
         _lib.check(rc, "occ_rawboost_fir_bank")
+
+
+# kernels on the hot path: a register spill in one of these costs tens of percent (a 20-byte spill in the default GEMM took the bench
+# from 10.2 to 12.1 ms before it was noticed), so the build's resource report is checked instead of waiting for a timing run
+_NO_SCRATCH = ["gemm_bf16_dma_kernelILi128ELb0ELi128", "gemm_bf16_dma_kernelILi128ELb1ELi128", "gemm_bf16_dma_kernelILi256", "gemm_bf16_hs_kernel",
+               "gemm_kernelILi2ELi64", "gemm_kernelILi2ELi128", "gemm_tn_bf16_kernel", "gemm_tn_dma_kernel", "attention_mfma_head_kernelILi7",
+               "attention_mfma_long_kernelILi64", "attention_mfma_kernelILi4", "conv0_ln_gelu_kernelItLi10", "layernorm_kernelIftLi2", "conv0_bwd_kernel",
+               "fir_bank_kernel", "adam_multi_kernel"]
+
+
+def test_hot_kernels_do_not_spill():
+    build_dir = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc", "_build")
+    reports = [f for f in (os.listdir(build_dir) if os.path.isdir(build_dir) else []) if f.endswith(".resources.txt")]
+    if not reports:                                   # library built by an older Makefile (or shipped prebuilt): rebuild to get the reports
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc"), "-B", "-j4"], check=True, capture_output=True)
+        reports = [f for f in os.listdir(build_dir) if f.endswith(".resources.txt")]
+    kernels, name = {}, None
+    for f in reports:
+        for line in open(os.path.join(build_dir, f)):
+            key, _, val = line.strip().partition(": ")
+            if key == "Function Name":
+                name = val
+                kernels[name] = {}
+            elif name:
+                kernels[name][key.split(" [")[0]] = val
+    assert len(kernels) > 100
+    for want in _NO_SCRATCH:
+        hits = [k for k in kernels if want in k]
+        assert hits, "no kernel matching %s in the build report" % want
+        for k in hits:
+            assert kernels[k]["ScratchSize"] == "0", "%s spills %s bytes per lane" % (k, kernels[k]["ScratchSize"])
