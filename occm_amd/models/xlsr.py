@@ -472,8 +472,16 @@ class XlsrFineTuner(XlsrFrontend):
         K.gemm_tn(M, N, Kd, dy, rowmap(M, 0, N), x, rowmap(M, 0, Kd), self.mg[gname], Kd, colsum_out=self.mg[bias_name], a_bf16=True, b_bf16=True,
                   bf16_mfma=True)
 
-    def backward(self, dfeats):
-        """dfeats f32 [B,T,dim] (gradient wrt the returned features) -> accumulates into self.G."""
+    def layer_grad_range(self, i):
+        """[lo, hi) of transformer layer i's gradients in the flat buffer self.G (its twelve tensors are contiguous)."""
+        lo = self.tslots["l%d.qkv.w" % i][0]
+        hi = self.tslots["l%d.qkv.w" % (i + 1)][0] if i + 1 < self.cfg.layers else self.tslots["enc_ln.g"][0]
+        return lo, hi
+
+    def backward(self, dfeats, grad_ready=None):
+        """dfeats f32 [B,T,dim] (gradient wrt the returned features) -> accumulates into self.G.
+        grad_ready(lo, hi): called after each transformer layer (last first) with the range of self.G that is now final, so a
+        data-parallel caller can start that slice's all-reduce under the rest of the backward pass."""
         if self.ctx is None:
             raise OccError("backward() needs a preceding forward_train()")
         cfg, w = self.cfg, self.w
@@ -500,6 +508,8 @@ class XlsrFineTuner(XlsrFrontend):
             self._wgrad(tr["dqkv"], s["h1"], 3 * D, D, M, "l%d.qkv.w" % i, "l%d.qkv.b" % i)
             ops.gemm_raw(M, D, 3 * D, tr["dqkv"], qmap, self.wT["l%d.qkv.w" % i], 3 * D, tr["dh"], xmap, bfc, bfc)
             ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i], dx_bf16=dxb)
+            if grad_ready is not None:
+                grad_ready(*self.layer_grad_range(i))
         self.ctx = None
 
 
@@ -660,9 +670,9 @@ class XlsrFullFineTuner(XlsrFineTuner):
         ops.gemm_raw(M, cg, cfg.pos_k * cg, xpad, pmap, w["pos.w"], cfg.pos_k * cg, ws["x"], rowmap(M, 0, D), OCC_F32, code, bias=w["pos.b"], act=ACT_GELU,
                      R=inner, r_map=pmap, r_dtype=code, a_seg=(cfg.pos_k, cg, D), groups=(G, cg, cg * cfg.pos_k * cg, cg), aux=cv["u_pos"])
 
-    def backward(self, dfeats):
+    def backward(self, dfeats, grad_ready=None):
         B, L = self.ctx
-        super().backward(dfeats)                       # leaves d(loss)/d(encoder input) in tr["dx"]
+        super().backward(dfeats, grad_ready=grad_ready)  # leaves d(loss)/d(encoder input) in tr["dx"]
         from .. import backend_ops as K
         from .._lib import check, lib, ptr, stream_ptr
         cfg, w = self.cfg, self.w

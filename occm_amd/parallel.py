@@ -37,28 +37,57 @@ def shard_groups(n_groups, rank, world):
 
 class FlatGradAllReducer:
     """Sum-all-reduce of one flat gradient tensor in buckets of ``bucket_bytes``; the 1/world scaling is folded into
-    the optimizer step (occ_adam_multi grad_scale) instead of an extra pass over the gradients."""
+    the optimizer step (occ_adam_multi grad_scale) instead of an extra pass over the gradients.
+
+    Overlap with backward: ``reduce_range(lo, hi)`` starts the collective for ``flat[lo:hi]`` as soon as the caller says
+    those gradients are final (the XLS-R backward reports each transformer layer when it is done, last layer first);
+    RCCL runs it on its own stream behind the kernels enqueued so far, under the rest of the backward pass.
+    ``all_reduce()`` then covers whatever has not been started and waits for everything."""
 
     def __init__(self, flat_grad, bucket_bytes=64 << 20, group=None):
         self.flat = flat_grad
         self.group = group
-        n = max(1, bucket_bytes // flat_grad.element_size())
-        self.buckets = [flat_grad[i:i + n] for i in range(0, flat_grad.numel(), n)]
+        self.bucket = max(1, bucket_bytes // flat_grad.element_size())
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._started, self._works = [], []
+
+    @property
+    def buckets(self):
+        n = self.bucket
+        return [self.flat[i:i + n] for i in range(0, self.flat.numel(), n)]
 
     @property
     def grad_scale(self):
         return 1.0 / self.world
 
+    def _launch(self, lo, hi):
+        for a in range(lo, hi, self.bucket):
+            b = min(a + self.bucket, hi)
+            self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def reduce_range(self, lo, hi):
+        """Gradients in flat[lo:hi] are final: start their all-reduce now (no-op on one rank)."""
+        if self.world == 1 or hi <= lo:
+            return
+        self._started.append((int(lo), int(hi)))
+        self._launch(int(lo), int(hi))
+
     def all_reduce(self, async_op=False):
         if self.world == 1:
             return []
-        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
-        if not async_op:
-            for w in works:
-                w.wait()
-            return []
-        return works
+        cur, n = 0, self.flat.numel()
+        for lo, hi in sorted(self._started):                 # whatever reduce_range() has not covered
+            if lo > cur:
+                self._launch(cur, lo)
+            cur = max(cur, hi)
+        if cur < n:
+            self._launch(cur, n)
+        works, self._works, self._started = self._works, [], []
+        if async_op:
+            return works
+        for w in works:
+            w.wait()
+        return []
 
 
 def max_over_ranks(value, device):

@@ -112,7 +112,9 @@ class OcTrainer:
         lc, demb = ops.compactness_loss(emb, n_groups=ng, group=self.group_size or B, scale=self.w_c, want_grad=True)
         ld, dlog = ops.ce_loss(logits, labels, scale=self.w_d, want_grad=True)
         dfeats = be.backward(demb, dlog, want_dfeats=True)
-        fe.backward(dfeats)
+        # each transformer layer's 50 MB of gradients go to RCCL as soon as that layer's backward is enqueued (last layer first);
+        # the conv stack, the back-end and anything left over follow at the end
+        fe.backward(dfeats, grad_ready=self.reducers[1].reduce_range if self.reducers[1].world > 1 else None)
         for r in self.reducers:
             r.all_reduce()
         self.opt.step(self._grads, grad_scale=self.reducer.grad_scale)

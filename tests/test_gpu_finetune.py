@@ -202,3 +202,33 @@ def test_full_finetuner_all_gradients_match_oracle_autograd(L):
     for k, v in p.items():
         assert tuple(ex[k].shape) == tuple(v.shape), k
         torch.testing.assert_close(ex[k].cpu(), v.detach())
+
+
+def test_backward_reports_layer_gradient_ranges_for_overlapped_allreduce():
+    """The data-parallel trainer starts each transformer layer's all-reduce when backward reports that slice of the flat gradient
+    final: the reports come last layer first, are disjoint, cover exactly the layers' tensors, and by the time a slice is reported
+    every kernel writing it has been enqueued (its contents, captured on the same stream, equal the end-of-backward contents)."""
+    from oracle import xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.models import xlsr
+    kw = dict(dim=256, ffn=512, heads=4, layers=3)
+    cfg = xlsr.XlsrConfig(**kw)
+    p = fill_like(xlsr_ref.param_shapes(xlsr_ref.XlsrConfig(**kw)), seed=3)
+    ft = xlsr.XlsrFullFineTuner(p, cfg)
+    wav = (0.1 * _r(2, 4000, seed=5)).cuda()
+    out = ft.forward_train(wav)
+    dfe = _r(*out.shape, seed=6).cuda()
+    ft.zero_grad()
+    seen, snaps = [], []
+
+    def ready(lo, hi):
+        seen.append((lo, hi))
+        snaps.append(ft.G[lo:hi].clone())            # stream-ordered copy, like the collective RCCL would enqueue here
+    ft.backward(dfe, grad_ready=ready)
+    assert [s for s in seen] == [ft.layer_grad_range(i) for i in (2, 1, 0)]
+    assert seen[2][0] == 0 and all(a[0] == b[1] for a, b in zip(seen, seen[1:]))       # contiguous, descending, no overlap
+    names = [n for n in ft.tslots if n.startswith("l1.")]
+    lo1, hi1 = ft.layer_grad_range(1)
+    assert all(lo1 <= ft.tslots[n][0] and ft.tslots[n][0] + ft.tslots[n][2] <= hi1 for n in names) and len(names) == 12
+    for (lo, hi), snap in zip(seen, snaps):
+        assert torch.equal(snap, ft.G[lo:hi]) and float(snap.abs().max()) > 0

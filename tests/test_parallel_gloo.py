@@ -28,6 +28,16 @@ def _worker(rank, world, port, out):
     for wk in works:
         wk.wait()
     ok = ok and torch.allclose(local, expect, atol=1e-6)
+    # overlapped form: slices reported ready out of order during "backward" (last layer first), the rest at the end, every element
+    # reduced exactly once
+    g2 = torch.Generator().manual_seed(100 + rank)
+    over = torch.randn(1000, generator=g2)
+    red2 = parallel.FlatGradAllReducer(over, bucket_bytes=400)          # 100-float buckets: ranges are split further
+    red2.reduce_range(700, 900); red2.reduce_range(400, 700); red2.reduce_range(0, 0)
+    red2.all_reduce()                                                   # covers [0,400) and [900,1000)
+    ok = ok and torch.allclose(over, expect, atol=1e-6) and red2._started == [] and red2._works == []
+    red2.all_reduce()                                                   # second step with nothing pre-started: one more full sum
+    ok = ok and torch.allclose(over, expect * world, atol=1e-5)
     mx = parallel.max_over_ranks(1.5 + rank, torch.device("cpu"))
     lo, hi = parallel.shard_groups(5, rank, world)
     parallel.barrier()
