@@ -321,6 +321,18 @@ int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
 int occ_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H,
                       int64_t hd, int64_t ld_qkv, int64_t ld_o, float scale, void* stream);
 
+/* ---- LFCC front-end (replaces utils.py:127-138 extract_lfcc -> spafe lfcc; parity unpinned: oracle/lfcc_ref.py) ----
+ * The DFT, the linear filter bank and the DCT run as f32 occ_gemm calls; these are the stages between them.
+ * frames [B*F, ld] = window * pre-emphasised samples (pe(n) = x[n] - c x[n-1]; zeros past the signal, columns frame_len..ld-1 zero).   */
+int occ_lfcc_frames(const float* wav, const float* window, float* frames, int64_t B, int64_t L, int64_t F, int64_t frame_len, int64_t hop,
+                    int64_t ld, float pre_emph, void* stream);
+/* spec rows = [re(0..nbins-1) | im(0..nbins-1)]; power[r,k] = scale (re^2 + im^2), columns nbins..ld_power-1 zeroed (GEMM K padding).      */
+int occ_lfcc_power(const float* spec, float* power, int64_t rows, int64_t nbins, int64_t ld_spec, int64_t ld_power, float scale, void* stream);
+/* x = log(x == 0 ? eps : x) in place (spafe zero_handling + numpy.log).                                                                    */
+int occ_log_eps(float* x, int64_t n, float eps, void* stream);
+/* normalize="mvn": per utterance and coefficient over its F frames, out = (x - mean) / population std.                                     */
+int occ_mvn_frames(const float* x, float* out, int64_t B, int64_t F, int64_t C, int64_t ld_x, int64_t ld_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

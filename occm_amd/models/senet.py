@@ -526,3 +526,40 @@ class ssl_resnet34(torch.nn.Module):
     def load_state_dict(self, sd, strict=True):
         self.resnet34.load_state_dict({k[len("resnet34."):]: v for k, v in sd.items() if k.startswith("resnet34.")})
         return self
+
+
+class LfccFrontend:
+    """Fixed (parameter-free) LFCC features: f32 waveform [B, L] -> f32 [B, n_frames, 13] (occm_amd.utils; reference utils.py:127-138)."""
+    out_dim = 13
+
+    def __init__(self, sr=16000):
+        self.sr = sr
+
+    def forward(self, wav, out_dtype=None, **kw):
+        from ..utils import extract_lfcc_batch
+        return extract_lfcc_batch(wav.contiguous(), self.sr)
+
+
+class lfcc_resnet34(torch.nn.Module):
+    """BASELINE configs[0]: LFCC [B,1,266,13] -> SE-ResNet34 -> (com [B,128], des [B,2]).  The reference has the two pieces
+    (utils.extract_lfcc; models/senet.py se_resnet34, whose SURVEY shape probe is exactly [B,1,266,13]) but no entry point that joins
+    them; this wrapper is that composition with the attribute names OcTrainer drives."""
+
+    def __init__(self, device="cuda", state_dict=None, seed=1, sr=16000, backend_compute="f32"):
+        super().__init__()
+        import types
+        self.frontend = LfccFrontend(sr)
+        self.resnet34 = se_resnet34(state_dict=state_dict, device=device, seed=seed, compute=backend_compute)
+        self.ssl_model = types.SimpleNamespace(model=self.frontend)
+        self.backend = self.resnet34.backend
+
+    def forward(self, x):
+        self.resnet34.train(self.training)
+        return self.resnet34(self.frontend.forward(x).unsqueeze(1))
+
+    def state_dict(self, *a, **kw):
+        return {"resnet34." + k: v for k, v in self.resnet34.state_dict().items()}
+
+    def load_state_dict(self, sd, strict=True):
+        self.resnet34.load_state_dict({k[len("resnet34."):]: v for k, v in sd.items() if k.startswith("resnet34.")})
+        return self
