@@ -271,6 +271,104 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-K inside the workgroup (under-filled long-K launches: fc2 at M = 6368 is 400 tiles x 64 slabs for 256 CUs): EIGHT waves per
+// 128x128 tile, waves 0-3 walk the first half of K and waves 4-7 the second half, each group with its own 32 KiB LDS image and the
+// default kernel's loop; at the end the upper group parks its accumulators in LDS (the two images are exactly the 64 KiB needed) and
+// the lower group adds them and runs the epilogue.  Twice the loads in flight per tile and half the K steps, a CU that owns one or two
+// tiles runs 8 / 16 waves instead of 4 / 8, and the sum order is fixed (no atomics: the frozen front-end stays bit-reproducible).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_bf16_ks2_kernel(const GemmArgs a) {
+    constexpr int ES = 2, CE = 8, SLAB_K = 64, TMT = 128;
+    constexpr int RPP = 32, XP = 4, WP = 4;                     // each group of 256 threads stages its own image as the default kernel does
+    __shared__ uint4 lds[2 * (TMT + TN) * CHUNKS];
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    if (a.group_m > 0) {
+        const int per_group = a.group_m * a.nbn;
+        const int gid = vid / per_group, first_m = gid * a.group_m;
+        const int gsz = a.nbm - first_m < a.group_m ? a.nbm - first_m : a.group_m;
+        const int loc = vid - gid * per_group;
+        tile_m = first_m + loc % gsz;
+        tile_n = loc / gsz;
+    }
+    const long long m0 = (long long)tile_m * TMT, n0 = (long long)tile_n * TN;
+    const int kh = threadIdx.x >> 8;                            // K half of this wave's group
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    uint4* ldsX = lds + kh * (TMT + TN) * CHUNKS; uint4* ldsW = ldsX + TMT * CHUNKS;
+    const long long grp = blockIdx.y;
+    const char* Xg = a.X + grp * a.a_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const long long cshift = grp * a.c_gstride;
+    const int pos = tid & 7, srow = tid >> 3;
+    const char* xsrc[XP]; const char* wsrc[WP];
+    const int ck = pos ^ (srow & 7);
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        long long m = m0 + srow + RPP * i; if (m > a.M - 1) m = a.M - 1;
+        xsrc[i] = Xg + row_off(a.xmap, m) * ES;
+        long long n = n0 + srow + RPP * i; if (n > a.N - 1) n = a.N - 1;
+        wsrc[i] = Wg + n * a.ldw * ES;
+    }
+    const int nhalf = (int)(a.K / SLAB_K) / 2;                  // slabs per K half (the launcher guarantees an even slab count)
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int sl = 0; sl < nhalf; ++sl) {
+        const long long k0 = (long long)(kh * nhalf + sl) * SLAB_K + ck * CE;
+        long long kx = k0;
+        if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
+#pragma unroll
+        for (int i = 0; i < XP; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx * ES), (lds_void*)&ldsX[(wave * 8 + RPP * i) * CHUNKS], 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + k0 * ES), (lds_void*)&ldsW[(wave * 8 + RPP * i) * CHUNKS], 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 wf[4], xf[4];
+            const int chk = kb * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = wn * 64 + i * 16 + fr;
+                wf[i] = ldsW[rw * CHUNKS + (chk ^ (rw & 7))];
+                const int rx = wm * 64 + i * 16 + fr;
+                xf[i] = ldsX[rx * CHUNKS + (chk ^ (rx & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // upper half -> LDS (lane-linear 16-byte slots: [wave][block][lane]), lower half adds in a fixed order and finishes the tile
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(wave * 16 + i * 4 + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += red[(wave * 16 + i * 4 + j) * 64 + lane];
+    gemm_epilogue<4>(a, acc, m0 + wm * 64, n0 + wn * 64, fr, fq, cshift);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Two-wave form of the 128x128 tile (experiment, variant 19): the same LDS image and DMA staging, but each of TWO waves owns 128 rows x
 // 64 columns (32 accumulators) instead of four waves owning 64x64: 8 + 4 fragment reads per 32 MFMAs instead of 4 + 4 per 16 (25 % fewer
 // ds_read bytes per FLOP), 8 waves per CU instead of 16.  Measured 7-25 % SLOWER than the default on every front-end shape: the default has
@@ -522,11 +620,13 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     // the 128x128 tile's finer granularity wins by 3-15 % (scripts/bench_gemm.py), so it stays the default there.
     const bool big = d->M >= 4096 && d->N >= 4096 && d->M % 256 == 0;
     int fam = -100;
-    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant != 1 && variant != 3 && variant != 4 && variant != 14 && variant != 19) {
+    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant != 1 && variant != 3 && variant != 4 && variant != 14 && variant != 19 && variant != 22) {
         fam = gemm_family_launch(variant, a, d, ng, s);          // experimental kernels live in gemm_family.hip
         if (fam != -100 && fam != OCC_OK) return fam;
     }
     if (fam == OCC_OK) {
+    } else if (d->ab_dtype == OCC_BF16 && d->K % 128 == 0 && variant == 22) {
+        hipLaunchKernelGGL(gemm_bf16_ks2_kernel, dim3((unsigned)total, (unsigned)ng), dim3(512), 0, s, a);
     } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 19) {
         hipLaunchKernelGGL(gemm_bf16_dma2_kernel<false>, dim3((unsigned)total, (unsigned)ng), dim3(128), 0, s, a);
     } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 14) {
@@ -553,6 +653,12 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         }
         // Under-filled launches with a long K (fc2 at M = 6368: 400 tiles for 1024 workgroup slots, 64 slabs each): the half-slab
         // pipeline keeps loads in flight under the MFMAs and wins 3-6 % there; with every slot busy the plain kernel is 15-20 % faster.
+        // Under-filled launches (at most two tiles per CU: fc2, out-proj, conv 5/6, proj at M = 6368): split K inside the workgroup.
+        // Measured against the kernels below: fc2 77 -> 65 us, out-proj 25.7 -> 23.7 us, conv5 27.0 -> 24.4 us; well-filled launches lose 10-15 %.
+        static const int ks2_env = getenv("OCC_GEMM_KS2") ? atoi(getenv("OCC_GEMM_KS2")) : 1;
+        if (split == 1 && variant == 1 && ks2_env && total * ng <= 2ll * cu_count() && nslab >= 8 && nslab % 2 == 0) {
+            hipLaunchKernelGGL(gemm_bf16_ks2_kernel, dim3((unsigned)total, (unsigned)ng), dim3(512), 0, s, a);
+        } else
         if (split == 1 && variant == 1 && total * ng <= 2ll * cu_count() && nslab >= 32) {
             hipLaunchKernelGGL(gemm_bf16_hs_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
         } else
