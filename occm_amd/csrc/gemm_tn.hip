@@ -262,16 +262,34 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_bf16_kernel(const TnArgs a) {
 //   * MFMA(a = X fragment, b = dY fragment): a lane ends with C[n1][n2 .. n2+3], i.e. 16-byte accesses to C;
 //   * the bias gradient (column sums of dY) is a separate colsum launch: fusing it (one MFMA per dY fragment against a fragment of
 //     ones) pushed the kernel over 128 VGPRs and cost 15-45 % of its run time.
+static inline long long cu_count_tn() {
+    static int n = 0;
+    if (!n) { int dev = 0, v = 0; n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }
+    return n;
+}
 typedef __attribute__((address_space(3))) void tn_lds_void;
 typedef __attribute__((address_space(1))) const void tn_gbl_void;
+//   * KG > 1: split of the reduction INSIDE the workgroup.  These products have few output tiles (fc1: 256, out-proj: 64) and a
+//     reduction of 12736 rows; with one 4-wave workgroup per tile a CU has one wave per SIMD and nothing hides the load latency, and
+//     splitting over workgroups costs f32 atomics (measured: every extra split adds ~20 us on a 1024x1024 output).  Here KG groups of
+//     four waves each take a contiguous part of the workgroup's rows with their own 32 KiB LDS image and the same loop; at the end the
+//     upper groups park their accumulators in LDS (pairwise tree: 64 KiB per parked group) and group 0 stores.  Fixed summation order.
 constexpr int TD = 128, SLD = 64;
-__global__ __launch_bounds__(256, 4) void gemm_tn_dma_kernel(const TnArgs a) {
-    __shared__ uint4 lds[2 * SLD * 16];                   // A slab (64 rows x 16 chunks), then B slab
+template <int KG>
+__global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_tn_dma_kernel(const TnArgs a) {
+    __shared__ uint4 lds_all[KG * 2 * SLD * 16];          // per group: A slab (64 rows x 16 chunks), then B slab
     int bx, by, bz; tn_block(a, bx, by, bz);
     const long long n1_0 = (long long)bx * TD, n2_0 = (long long)by * TD;
-    const long long m_begin = (long long)bz * a.rows_per_split;
-    const long long m_end = m_begin + a.rows_per_split < a.M ? m_begin + a.rows_per_split : a.M;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long wg_begin = (long long)bz * a.rows_per_split;
+    const long long wg_end = wg_begin + a.rows_per_split < a.M ? wg_begin + a.rows_per_split : a.M;
+    const int kg = KG > 1 ? threadIdx.x >> 8 : 0;
+    // every group runs the same number of slabs (the barriers are workgroup-wide); a group whose rows are used up stages zeros
+    const long long rows_per_group = KG > 1 ? ((wg_end - wg_begin + KG - 1) / KG + SLD - 1) / SLD * SLD : wg_end - wg_begin;
+    const long long m_begin = wg_begin + kg * rows_per_group;
+    const long long m_end = m_begin + rows_per_group < wg_end ? m_begin + rows_per_group : wg_end;     // may be <= m_begin
+    const int nsl = (int)((rows_per_group + SLD - 1) / SLD);
+    uint4* lds = lds_all + kg * 2 * SLD * 16;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
     long long bseg_off = n2_0;
     if (a.nseg > 1) { const long long sg = n2_0 / a.seg_len; bseg_off = sg * a.seg_stride + (n2_0 - sg * a.seg_len); }
@@ -294,17 +312,18 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_dma_kernel(const TnArgs a) {
     unsigned char* ldsA = reinterpret_cast<unsigned char*>(lds);
     unsigned char* ldsB = ldsA + SLD * 256;
     typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
-    for (long long m0 = m_begin; m0 < m_end; m0 += SLD) {
+    for (int sl = 0; sl < nsl; ++sl) {
+        const long long m0 = m_begin + (long long)sl * SLD;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ii = i * 4 + wave;
-            long long m = m0 + 4 * ii + rl; if (m > m_end - 1) m = m_end - 1;
+            long long m = m0 + 4 * ii + rl; if (m > wg_end - 1) m = wg_end - 1;
             const long long oa = plain ? m * a.amap.rstride : row_off(a.amap, m), ob = plain ? m * a.bmap.rstride : row_off(a.bmap, m);
             __builtin_amdgcn_global_load_lds((tn_gbl_void*)(Ap + oa), (tn_lds_void*)&lds[ii * 64], 16, 0, 0);
             __builtin_amdgcn_global_load_lds((tn_gbl_void*)(Bp + ob), (tn_lds_void*)&lds[SLD * 16 + ii * 64], 16, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (m0 + SLD > m_end) {                             // last, partial slab: rows past the end must not contribute
+        if (m0 + SLD > m_end) {                             // partial (or, for a used-up group, empty) slab: rows past the end must not contribute
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ii = i * 4 + wave;
@@ -333,6 +352,29 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_dma_kernel(const TnArgs a) {
                 for (int ib = 0; ib < 4; ++ib) acc[ia][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ib], af[ia], acc[ia][ib], 0, 0, 0);
         }
         __syncthreads();
+    }
+    if constexpr (KG > 1) {
+        // pairwise tree over the groups: the upper half parks its accumulators (64 KiB per group = two groups' slab images), the lower
+        // half adds them; the whole LDS is free after the loop's last barrier
+        f32x4* red = reinterpret_cast<f32x4*>(lds_all);
+#pragma unroll
+        for (int half = KG / 2; half >= 1; half >>= 1) {
+            if (kg >= half && kg < 2 * half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) red[(((kg - half) * 4 + wave) * 16 + i * 4 + j) * 64 + lane] = acc[i][j];
+            }
+            __syncthreads();
+            if (kg < half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += red[((kg * 4 + wave) * 16 + i * 4 + j) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (kg != 0) return;
     }
     // D[row = n2 (4g + r)][col = n1 (fr)]: this lane owns C[n1][n2 .. n2+3]
 #pragma unroll
@@ -439,15 +481,25 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
         d->a_map.row_stride % 8 == 0 && d->a_map.batch_stride % 8 == 0 && d->a_map.line_stride % 8 == 0 &&
         d->b_map.row_stride % 8 == 0 && d->b_map.batch_stride % 8 == 0 && d->b_map.line_stride % 8 == 0 && (nseg == 1 || d->b_seg_stride % 8 == 0)) {
         const long long u1 = occ_cdiv(d->N1, TD), u2 = occ_cdiv(d->N2, TD);
-        long long sp = occ_cdiv(512, u1 * u2);                          // ~2 workgroups per CU: the f32 atomics of a split are not free
-        const long long msp = d->M / 256;
+        // KG groups of four waves split the rows inside a workgroup (no atomics between them); workgroups beyond one per tile split the
+        // rows further and do need atomics, so there are only as many as it takes to have ~one 16-wave workgroup per CU
+        // Measured (scripts/bench_tn_kg.py, 48-tile outputs): KG = 4 wins up to ~50 k reduction rows (12736 rows: 113 -> 61 us; the
+        // transformer gradients at 12736 rows: 251 -> 150 us), beyond ~100 k rows many independent 4-wave workgroups win (409536 rows: 1.0 vs 1.9 ms)
+        static const int kg_env = getenv("OCC_TN_KG") ? atoi(getenv("OCC_TN_KG")) : 0;
+        static const long long dma_target = getenv("OCC_TN_DMA_TARGET") ? atoll(getenv("OCC_TN_DMA_TARGET")) : 0;
+        const int KGv = kg_env == 1 || kg_env == 2 || kg_env == 4 ? kg_env : (d->M <= 65536 ? 4 : 1);
+        long long sp = occ_cdiv(dma_target > 0 ? dma_target : (KGv == 1 ? 512 : 2 * cu_count_tn() / KGv * 1), u1 * u2);
+        const long long msp = d->M / (256 * KGv);
         if (sp > msp) sp = msp;
         if (sp < 1) sp = 1;
         a.rows_per_split = occ_cdiv(occ_cdiv(d->M, sp), SLD) * SLD;
         sp = occ_cdiv(d->M, a.rows_per_split);
         a.t1 = (int)u1; a.t2 = (int)u2; a.atomic = sp > 1;
         OCC_CHECK_ARG(u1 * u2 * sp < (1ll << 30), "occ_gemm_tn: output too large");
-        hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3((unsigned)(u1 * u2 * sp)), dim3(THREADS), 0, (hipStream_t)stream, a);
+        const dim3 grid((unsigned)(u1 * u2 * sp));
+        if (KGv == 4) hipLaunchKernelGGL(gemm_tn_dma_kernel<4>, grid, dim3(1024), 0, (hipStream_t)stream, a);
+        else if (KGv == 2) hipLaunchKernelGGL(gemm_tn_dma_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(gemm_tn_dma_kernel<1>, grid, dim3(THREADS), 0, (hipStream_t)stream, a);
         if (a.colsum) launch_colsum_bf16_vec((const unsigned short*)a.A, a.amap, a.M, a.N1, a.colsum, a.alpha, (hipStream_t)stream);
         OCC_LAUNCH_CHECK("occ_gemm_tn");
         return OCC_OK;

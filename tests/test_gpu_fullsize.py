@@ -24,7 +24,12 @@ def test_frontend_300m_utterances_are_independent_and_order_equivariant(fe300):
     full = fe300.forward(wav, out_dtype=torch.float32).clone()
     assert full.shape == (8, 199, 1024) and bool(torch.isfinite(full).all())
     one = fe300.forward(wav[3:4], out_dtype=torch.float32).clone()
-    torch.testing.assert_close(one[0], full[3], rtol=0, atol=0)            # same K-loop order per output element: bit-identical
+    # A different batch size can select a different GEMM kernel (under-filled launches split K inside the workgroup), i.e. another
+    # summation order: equal to bf16 round-off carried through 24 layers, not bit-equal.  Same shape = same kernels = bit-equal (below).
+    d = (one[0] - full[3]).abs()
+    assert float(d.max()) < 8e-2 and float(d.mean()) < 4e-3, (float(d.max()), float(d.mean()))
+    again = fe300.forward(wav[3:4], out_dtype=torch.float32)
+    torch.testing.assert_close(again, one, rtol=0, atol=0)                 # run-to-run: bit-identical (no atomics on this path)
     perm = torch.tensor([5, 2, 7, 0, 1, 6, 3, 4], device="cuda")
     shuf = fe300.forward(wav[perm].contiguous(), out_dtype=torch.float32)
     torch.testing.assert_close(shuf, full[perm], rtol=0, atol=0)
@@ -37,7 +42,8 @@ def test_frontend_300m_batch32_matches_two_halves(fe300):
     full = fe300.forward(wav, out_dtype=torch.float32).clone()
     lo = fe300.forward(wav[:16].contiguous(), out_dtype=torch.float32).clone()
     hi = fe300.forward(wav[16:].contiguous(), out_dtype=torch.float32)
-    torch.testing.assert_close(torch.cat([lo, hi]), full, rtol=0, atol=0)
+    d = (torch.cat([lo, hi]) - full).abs()                                 # bs 16 and bs 32 may take different GEMM kernels: round-off level, see above
+    assert float(d.max()) < 8e-2 and float(d.mean()) < 4e-3, (float(d.max()), float(d.mean()))
 
 
 def test_backend_bs32_eval_is_order_equivariant():
