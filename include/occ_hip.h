@@ -333,6 +333,14 @@ int occ_log_eps(float* x, int64_t n, float eps, void* stream);
 /* normalize="mvn": per utterance and coefficient over its F frames, out = (x - mean) / population std.                                     */
 int occ_mvn_frames(const float* x, float* out, int64_t B, int64_t F, int64_t C, int64_t ld_x, int64_t ld_out, void* stream);
 
+/* ---- input pipeline: FLAC decode on the host (replaces librosa.load -> libsndfile at oc_training.py:214, 234,
+ * oc_classifier.py:93, data_utils_SSL.py:66, 91).  No GPU work.  buf = the whole file in host memory.
+ * occ_flac_info: info[0..3] = sample rate, channels, bits per sample, 1 if STREAMINFO carries an MD5; total = samples per channel
+ * (0 = unknown); md5 (optional) = the 16 signature bytes.  occ_flac_decode: out = interleaved int32 [capacity * channels],
+ * *decoded = samples per channel written; frame-header CRC-8 and frame CRC-16 are verified (OCC_EINVAL + occ_last_error on mismatch).   */
+int occ_flac_info(const uint8_t* buf, int64_t n, int32_t* info, int64_t* total, uint8_t* md5);
+int occ_flac_decode(const uint8_t* buf, int64_t n, int32_t* out, int64_t capacity, int64_t* decoded);
+
 #ifdef __cplusplus
 }
 #endif

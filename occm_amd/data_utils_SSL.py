@@ -48,6 +48,8 @@ def load_audio(path, sr=16000):
             if w.getnchannels() > 1:
                 data = data.reshape(-1, w.getnchannels()).mean(axis=1)
             return data, w.getframerate()
+    if path.lower().endswith(".flac") and os.path.exists(path):
+        return read_flac(path)
     try:
         import soundfile as sf
         data, fs = sf.read(path, dtype="float32")
@@ -55,6 +57,40 @@ def load_audio(path, sr=16000):
     except ImportError:
         import librosa
         return librosa.load(path, sr=sr)
+
+
+def decode_flac_bytes(raw, verify_md5=True):
+    """FLAC file contents -> (int32 [n, channels], sample rate, bits per sample) through the library's host decoder
+    (occ_flac_info / occ_flac_decode: frame CRCs checked there).  The STREAMINFO MD5 of the decoded PCM is checked here,
+    so a stream the decoder misreads raises instead of returning noise."""
+    import ctypes
+    import hashlib
+    from ._lib import check, lib
+    buf = (ctypes.c_uint8 * len(raw)).from_buffer_copy(raw)
+    info = (ctypes.c_int32 * 4)(); total = ctypes.c_int64(0); md5 = (ctypes.c_uint8 * 16)()
+    check(lib().occ_flac_info(buf, len(raw), info, ctypes.byref(total), md5), "occ_flac_info")
+    fs, nch, bps, has_md5 = info[0], info[1], info[2], info[3]
+    cap = total.value if total.value > 0 else max(1, len(raw) * 8)          # unknown length: a sample takes at least one bit
+    out = np.empty((cap, nch), dtype=np.int32)
+    got = ctypes.c_int64(0)
+    check(lib().occ_flac_decode(buf, len(raw), out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(got)), "occ_flac_decode")
+    out = out[:got.value]
+    if total.value and got.value != total.value:
+        raise ValueError("FLAC stream ended after %d of %d samples" % (got.value, total.value))
+    if verify_md5 and has_md5:
+        nbytes = (bps + 7) // 8                                              # signature = MD5 of the interleaved little-endian samples
+        le = out.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :nbytes]
+        if hashlib.md5(np.ascontiguousarray(le).tobytes()).digest() != bytes(md5):
+            raise ValueError("FLAC MD5 signature mismatch: the decoded audio is not what the encoder saw")
+    return out, fs, bps
+
+
+def read_flac(path):
+    """-> (float32 mono in [-1, 1), sample rate), like the wav branch above (channels averaged, no resampling)."""
+    with open(path, "rb") as f:
+        pcm, fs, bps = decode_flac_bytes(f.read())
+    x = pcm.astype(np.float32) / float(1 << (bps - 1))
+    return (x.mean(axis=1) if x.shape[1] > 1 else x[:, 0]), fs
 
 
 def process_Rawboost_feature(feature, sr, args, algo):

@@ -1,0 +1,92 @@
+"""Host FLAC decoder of the input pipeline (occ_flac_info / occ_flac_decode through occm_amd.data_utils_SSL) against streams written by the
+test-only encoder tests/flac_writer.py: bit-exact PCM for every subframe type and stereo mode, CRC / MD5 failures are reported.
+No GPU needed (the decoder is host code inside libocc_hip.so).  Not validated against libFLAC-encoded files: none exist in this image."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import flac_writer as fw
+from occm_amd import data_utils_SSL as du
+
+
+def _speechlike(n, nch=1, seed=0, bps=16):
+    g = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    x = np.stack([0.3 * np.sin(2 * np.pi * (220 + 40 * c) * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.02 * g.standard_normal(n) for c in range(nch)], 1)
+    return np.round(x * (1 << (bps - 1)) * 0.9).astype(np.int64)
+
+
+@pytest.mark.parametrize("kind", ["verbatim", "fixed0", "fixed1", "fixed2", "fixed3", "fixed4", "lpc"])
+@pytest.mark.parametrize("method,porder", [(0, 0), (0, 3), (1, 2)])
+def test_subframe_types_and_rice_partitions_roundtrip(kind, method, porder):
+    pcm = _speechlike(9000, 1, seed=1)
+    lpc = ([1876, -1012, 205, -61, 17, 9, -4, 2], 12, 10) if kind == "lpc" else None        # any coefficients give a valid stream
+    raw = fw.encode(pcm, blocksize=4096, kinds=(kind,), method=method, porder=porder, lpc=lpc)
+    out, fs, bps = du.decode_flac_bytes(raw)
+    assert (fs, bps) == (16000, 16) and out.shape == (9000, 1)
+    np.testing.assert_array_equal(out[:, 0], pcm[:, 0])
+
+
+@pytest.mark.parametrize("stereo", ["independent", "left_side", "side_right", "mid_side"])
+def test_stereo_decorrelation_modes(stereo):
+    pcm = _speechlike(5000, 2, seed=2)
+    pcm[:, 1] = pcm[:, 0] // 2 + pcm[:, 1] // 3                                # correlated channels, odd/even sums for the mid/side LSB
+    raw = fw.encode(pcm, blocksize=1152, kinds=("fixed2", "fixed1"), stereo=stereo, porder=2)
+    out, fs, bps = du.decode_flac_bytes(raw)
+    np.testing.assert_array_equal(out, pcm)
+
+
+def test_escape_partitions_constant_frames_wasted_bits_and_odd_block_sizes():
+    pcm = _speechlike(3 * 700 + 123, 1, seed=3)
+    raw = fw.encode(pcm, blocksize=700, kinds=("fixed2",), method=0, porder=0, force_escape=True)       # 16-bit explicit block size, raw partitions
+    np.testing.assert_array_equal(du.decode_flac_bytes(raw)[0][:, 0], pcm[:, 0])
+    raw = fw.encode(pcm[:600], blocksize=200, kinds=("fixed1",), variable=True)                           # 8-bit explicit size, sample-numbered frames
+    np.testing.assert_array_equal(du.decode_flac_bytes(raw)[0][:, 0], pcm[:600, 0])
+    z = np.zeros((5000, 1), dtype=np.int64); z[4096:] = -7
+    raw = fw.encode(z, blocksize=4096, kinds=("constant",))                                               # digital silence, then a constant tail
+    np.testing.assert_array_equal(du.decode_flac_bytes(raw)[0], z)
+    w = (_speechlike(4096, 1, seed=4) >> 3) << 3                                                          # three wasted bits per sample
+    raw = fw.encode(w, kinds=("fixed2+wasted",))
+    np.testing.assert_array_equal(du.decode_flac_bytes(raw)[0], w)
+    big = _speechlike(4096, 2, seed=5, bps=24)                                                            # 24-bit: 25-bit side channel
+    raw = fw.encode(big, bps=24, kinds=("fixed2",), stereo="mid_side", method=1, porder=1)
+    out, fs, bps = du.decode_flac_bytes(raw)
+    assert bps == 24
+    np.testing.assert_array_equal(out, big)
+
+
+def test_corruption_is_reported_not_returned():
+    pcm = _speechlike(6000, 1, seed=6)
+    raw = bytearray(fw.encode(pcm, blocksize=1024, kinds=("fixed2",), porder=1))
+    bad = bytearray(raw); bad[len(bad) // 2] ^= 0x10                                                      # a flipped bit inside a frame
+    with pytest.raises(Exception) as e:
+        du.decode_flac_bytes(bytes(bad))
+    assert "CRC" in str(e.value) or "subframe" in str(e.value) or "sync" in str(e.value)
+    wrong = bytearray(raw); wrong[8 + 18] ^= 0xff                                                         # first MD5 byte of STREAMINFO
+    with pytest.raises(ValueError, match="MD5"):
+        du.decode_flac_bytes(bytes(wrong))
+    with pytest.raises(Exception, match="fLaC"):
+        du.decode_flac_bytes(b"RIFF" + bytes(100))
+    with pytest.raises(Exception):
+        du.decode_flac_bytes(bytes(raw[:len(raw) // 2]))                                                  # truncated file: fewer samples than STREAMINFO says
+
+
+def test_load_audio_reads_flac_like_wav(tmp_path):
+    import wave
+    pcm = _speechlike(16000, 1, seed=7)
+    p = tmp_path / "LA_T_1000137.flac"
+    p.write_bytes(fw.encode(pcm, blocksize=4096, kinds=("lpc", "fixed2"), porder=3, lpc=([1520, -640, 90], 12, 10)))
+    x, fs = du.load_audio(str(p))
+    assert fs == 16000 and x.dtype == np.float32 and x.shape == (16000,)
+    wp = tmp_path / "same.wav"
+    with wave.open(str(wp), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.astype("<i2").tobytes())
+    y, fs2 = du.load_audio(str(wp))
+    assert fs2 == 16000
+    np.testing.assert_array_equal(x, y)
+    st = _speechlike(3000, 2, seed=8)
+    p2 = tmp_path / "stereo.flac"
+    p2.write_bytes(fw.encode(st, blocksize=1024, stereo="left_side"))
+    m, _ = du.load_audio(str(p2))
+    np.testing.assert_allclose(m, st.mean(1) / 32768.0, atol=1e-7)
