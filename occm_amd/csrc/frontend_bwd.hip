@@ -3,6 +3,7 @@
 // TransformerSentenceEncoderLayer (pre-LN) reached from models/sslassist.py:48 when the optimizer holds the SSL
 // parameters (oc_training.py:324).
 #include "occ_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -45,14 +46,24 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const TS* __restric
 //   dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) (+ dres);  dgamma += sum dy*xhat;  dbeta += sum dy.
 template <typename T> struct LVec8;
 template <> struct LVec8<float> {
+    struct raw_t { float4 a, b; };
     static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
         const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
+    // raw load now, convert at use: lets the next row's loads fly under the current row's reductions
+    static __device__ __forceinline__ raw_t load_raw(const float* p) { return raw_t{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)}; }
+    static __device__ __forceinline__ raw_t zero_raw() { return raw_t{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}; }
+    static __device__ __forceinline__ void convert(const raw_t& r, float (&v)[8]) {
+        v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+    }
 };
 template <> struct LVec8<unsigned short> {
-    static __device__ __forceinline__ void load(const unsigned short* p, float (&v)[8]) {
-        const uint4 a = *reinterpret_cast<const uint4*>(p);
+    typedef uint4 raw_t;
+    static __device__ __forceinline__ void load(const unsigned short* p, float (&v)[8]) { convert(*reinterpret_cast<const uint4*>(p), v); }
+    static __device__ __forceinline__ raw_t load_raw(const unsigned short* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ raw_t zero_raw() { return make_uint4(0, 0, 0, 0); }
+    static __device__ __forceinline__ void convert(const raw_t& a, float (&v)[8]) {
         const unsigned w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
@@ -77,21 +88,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
         for (int e = 0; e < 8; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; g[it][e] = 0.f; bt[it][e] = 0.f; }
         if (c < C) { LVec8<float>::load(gamma + c, g[it]); if (GELU) LVec8<float>::load(beta + c, bt[it]); }
     }
+    // The grid is one 4-wave workgroup per CU (more workgroups means more dgamma / dbeta atomics on the same 2C addresses, measured slower),
+    // so a wave has no neighbours on its SIMD to hide latency: the NEXT row's x / dy and THIS row's residual gradient are loaded (raw)
+    // at the top of an iteration and converted only when used, i.e. they fly under the four dependent wave reductions of the row.
+    typename LVec8<TX>::raw_t nx[NIT]; typename LVec8<TDY>::raw_t nd[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = (it * 64 + lane) * 8;
+        nx[it] = LVec8<TX>::zero_raw(); nd[it] = LVec8<TDY>::zero_raw();
+        if (c < C && wave0 < rows) { nx[it] = LVec8<TX>::load_raw(x + wave0 * C + c); nd[it] = LVec8<TDY>::load_raw(dy + wave0 * C + c); }
+    }
     for (long long row = wave0; row < rows; row += nwaves) {
         float xv[NIT][8], dv[NIT][8];
+        LVec8<float>::raw_t rr[NIT];
         float s = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int c = (it * 64 + lane) * 8;
-            if (c < C) {
-                LVec8<TX>::load(x + row * C + c, xv[it]);
-                LVec8<TDY>::load(dy + row * C + c, dv[it]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { xv[it][e] = 0.f; dv[it][e] = 0.f; }
-            }
+            LVec8<TX>::convert(nx[it], xv[it]);
+            LVec8<TDY>::convert(nd[it], dv[it]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += xv[it][e];
+        }
+        {
+            const long long nrow = row + nwaves;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = (it * 64 + lane) * 8;
+                rr[it] = LVec8<float>::zero_raw();
+                if (c < C) {
+                    if (dres) rr[it] = LVec8<float>::load_raw(dres + row * C + c);
+                    if (nrow < rows) { nx[it] = LVec8<TX>::load_raw(x + nrow * C + c); nd[it] = LVec8<TDY>::load_raw(dy + nrow * C + c); }
+                }
+            }
         }
         const float mean = wave_sum(s) / (float)C;
         float q = 0.f;
@@ -122,7 +150,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
             const int c = (it * 64 + lane) * 8;
             if (c < C) {
                 float v[8], r[8];
-                if (dres) LVec8<float>::load(dres + row * C + c, r);
+                LVec8<float>::convert(rr[it], r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     v[e] = rstd * (dv[it][e] * g[it][e] - s1 - xv[it][e] * s2);
@@ -537,7 +565,8 @@ int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
     OCC_CHECK_ARG(rows >= 1 && C >= 8 && C % 8 == 0 && C <= 2048, "occ_layernorm_bwd: C must be a multiple of 8 in [8,2048]");
     OCC_CHECK_ARG((dy_dtype == OCC_F32 || dy_dtype == OCC_BF16) && (x_dtype == OCC_F32 || x_dtype == OCC_BF16), "occ_layernorm_bwd: dy / x must be f32 or bf16");
     long long blocks = occ_cdiv(rows, 4 * 8);           // >= 8 rows per wave so the per-workgroup atomics amortise
-    if (blocks > 256) blocks = 256;
+    static const long long lnb_blocks = getenv("OCC_LNB_BLOCKS") ? atoll(getenv("OCC_LNB_BLOCKS")) : 256;
+    if (blocks > lnb_blocks) blocks = lnb_blocks;
     if (blocks < 1) blocks = 1;
     const int nit = (int)((C + 511) / 512);
     OCC_CHECK_ARG(nit <= 2 || !gelu, "occ_layernorm_bwd: fused GELU supports C <= 1024");
