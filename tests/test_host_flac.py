@@ -6,7 +6,10 @@ import os
 import numpy as np
 import pytest
 
-from tests import flac_writer as fw
+try:
+    from tests import flac_writer as fw
+except ImportError:                                   # run as plain `pytest`: tests/ itself is on sys.path
+    import flac_writer as fw
 from occm_amd import data_utils_SSL as du
 
 
