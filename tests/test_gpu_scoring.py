@@ -18,6 +18,19 @@ def _write_wav(path, n, seed):
         w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.tobytes())
 
 
+def _write_flac(path, n, seed):
+    """The evaluation side of the corpus as real FLAC (the ASVspoof corpora are .flac): written by the test-only encoder, read back by
+    the library's host decoder inside ASVDataset.  Returns the samples the oracle should see."""
+    try:
+        from tests import flac_writer as fw
+    except ImportError:
+        import flac_writer as fw
+    x = (np.clip(synth_wave(seed, n), -1, 1) * 32767).astype(np.int16)
+    with open(path, "wb") as f:
+        f.write(fw.encode(x.astype(np.int64)[:, None], blocksize=4096, kinds=("lpc", "fixed2"), porder=3, lpc=([1520, -640, 90], 12, 10)))
+    return x.astype(np.float32) / 32768.0
+
+
 def test_reference_embedding_threshold_and_scores_match_oracle(tmp_path, monkeypatch):
     from oracle import aasist_ref, losses_ref, xlsr_ref
     from oracle.fill import fill_like
@@ -32,8 +45,9 @@ def test_reference_embedding_threshold_and_scores_match_oracle(tmp_path, monkeyp
     for i in range(5):
         _write_wav(str(d / f"T{i}.wav"), 9000 + 400 * i, 10 + i)
         tr_lines.append(f"LA_{i} T{i} - - {'bonafide' if i != 2 else 'spoof'}")
+    eval_pcm = {}
     for i in range(4):
-        _write_wav(str(d / f"E{i}.wav"), 8000 + 700 * i, 50 + i)
+        eval_pcm[i] = _write_flac(str(d / f"E{i}.flac"), 8000 + 700 * i, 50 + i)
         ev_lines.append(f"E{i}")
     (tmp_path / "train.txt").write_text("\n".join(tr_lines) + "\n")
     (tmp_path / "eval.txt").write_text("\n".join(ev_lines) + "\n")
@@ -48,7 +62,7 @@ def test_reference_embedding_threshold_and_scores_match_oracle(tmp_path, monkeyp
     score_eval_set_1c2(model, ev, "cuda", ref_emb, thr)
 
     def oracle_emb(path):
-        x, _ = load_audio(path)
+        x = eval_pcm[int(os.path.basename(path)[1])] if path.endswith(".flac") else load_audio(path)[0]
         with torch.no_grad():
             f = xlsr_ref.extract_feat(torch.tensor(x)[None], px, rcfg)
             return aasist_ref.backend_forward(f, pb, train=False)[0]
@@ -63,7 +77,7 @@ def test_reference_embedding_threshold_and_scores_match_oracle(tmp_path, monkeyp
     assert len(lines) == 4
     for i, line in enumerate(lines):
         dist, flag = line.split(",")
-        od = float(losses_ref.pairwise_l2(o_ref, oracle_emb(str(d / f"E{i}.wav"))))
+        od = float(losses_ref.pairwise_l2(o_ref, oracle_emb(str(d / f"E{i}.flac"))))
         assert abs(float(dist) - od) < 2e-3 and line.endswith(" ")
         assert int(flag) == int(float(dist) > float(thr))
 
