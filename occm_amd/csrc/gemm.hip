@@ -271,6 +271,82 @@ __global__ __launch_bounds__(2 * TMT, 2 * TMT == 256 ? 4 : 2) void gemm_bf16_dma
 }
 
 // ------------------------------------------------------------------------------------------------
+// Narrow outputs (N <= 64 per group: the grouped positional conv has 16 groups of 64 output channels): a 128x64 tile, the four waves
+// stacked along M (32 rows x 64 columns each, 8 accumulators).  In the 128x128 kernel half of every W image and half of the MFMAs
+// of such a launch are padding; here the image is 16 + 8 KiB and a wave needs ~70 registers, so five workgroups share a CU.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void gemm_bf16_dma_n64_kernel(const GemmArgs a) {
+    constexpr int ES = 2, CE = 8, SLAB_K = 64, TMT = 128, TNT = 64;
+    constexpr int RPP = 32, XP = TMT / RPP, WP = TNT / RPP;
+    __shared__ uint4 lds[(TMT + TNT) * CHUNKS];
+    uint4* ldsX = lds; uint4* ldsW = lds + TMT * CHUNKS;
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
+    const long long m0 = (long long)tile_m * TMT, n0 = (long long)tile_n * TNT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long grp = blockIdx.y;
+    const char* Xg = a.X + grp * a.a_gstride * ES;
+    const char* Wg = a.W + grp * a.w_gstride * ES;
+    const long long cshift = grp * a.c_gstride;
+    const int pos = tid & 7, srow = tid >> 3;
+    const int ck = pos ^ (srow & 7);
+    const char* xsrc[XP]; const char* wsrc[WP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        long long m = m0 + srow + RPP * i; if (m > a.M - 1) m = a.M - 1;
+        xsrc[i] = Xg + row_off(a.xmap, m) * ES;
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        long long n = n0 + srow + RPP * i; if (n > a.N - 1) n = a.N - 1;
+        wsrc[i] = Wg + n * a.ldw * ES;
+    }
+    const int nslab = (int)(a.K / SLAB_K);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int slab = 0; slab < nslab; ++slab) {
+        const long long k0 = (long long)slab * SLAB_K + ck * CE;
+        long long kx = k0;
+        if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
+#pragma unroll
+        for (int i = 0; i < XP; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx * ES), (lds_void*)&ldsX[(wave * 8 + RPP * i) * CHUNKS], 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + k0 * ES), (lds_void*)&ldsW[(wave * 8 + RPP * i) * CHUNKS], 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 wf[4], xf[2];
+            const int chk = kb * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = i * 16 + fr;
+                wf[i] = ldsW[rw * CHUNKS + (chk ^ (rw & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rx = wave * 32 + j * 16 + fr;
+                xf[j] = ldsX[rx * CHUNKS + (chk ^ (rx & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<2>(a, acc, m0 + wave * 32, n0, fr, fq, cshift);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Split-K inside the workgroup (under-filled long-K launches: fc2 at M = 6368 is 400 tiles x 64 slabs for 256 CUs): EIGHT waves per
 // 128x128 tile, waves 0-3 walk the first half of K and waves 4-7 the second half, each group with its own 32 KiB LDS image and the
 // default kernel's loop; at the end the upper group parks its accumulators in LDS (the two images are exactly the 64 KiB needed) and
@@ -653,9 +729,14 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         }
         // Under-filled launches with a long K (fc2 at M = 6368: 400 tiles for 1024 workgroup slots, 64 slabs each): the half-slab
         // pipeline keeps loads in flight under the MFMAs and wins 3-6 % there; with every slot busy the plain kernel is 15-20 % faster.
+        static const int n64_env = getenv("OCC_GEMM_N64") ? atoi(getenv("OCC_GEMM_N64")) : 1;
         // Under-filled launches (at most two tiles per CU: fc2, out-proj, conv 5/6, proj at M = 6368): split K inside the workgroup.
         // Measured against the kernels below: fc2 77 -> 65 us, out-proj 25.7 -> 23.7 us, conv5 27.0 -> 24.4 us; well-filled launches lose 10-15 %.
         static const int ks2_env = getenv("OCC_GEMM_KS2") ? atoi(getenv("OCC_GEMM_KS2")) : 1;
+        if (split == 1 && variant == 1 && n64_env && d->N <= 64) {          // narrow (grouped) outputs: 128x64 tile, no padded half
+            a.nbn = 1;
+            hipLaunchKernelGGL(gemm_bf16_dma_n64_kernel, dim3((unsigned)a.nbm, (unsigned)ng), dim3(THREADS), 0, s, a);
+        } else
         if (split == 1 && variant == 1 && ks2_env && total * ng <= 2ll * cu_count() && nslab >= 8 && nslab % 2 == 0) {
             hipLaunchKernelGGL(gemm_bf16_ks2_kernel, dim3((unsigned)total, (unsigned)ng), dim3(512), 0, s, a);
         } else

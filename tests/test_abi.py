@@ -37,7 +37,7 @@ def test_host_argument_validation_needs_no_gpu():
 
 # kernels on the hot path: a register spill in one of these costs tens of percent (a 20-byte spill in the default GEMM took the bench
 # from 10.2 to 12.1 ms before it was noticed), so the build's resource report is checked instead of waiting for a timing run
-_NO_SCRATCH = ["gemm_bf16_dma_kernelILi128ELb0ELi128", "gemm_bf16_dma_kernelILi128ELb1ELi128", "gemm_bf16_dma_kernelILi256", "gemm_bf16_hs_kernel", "gemm_bf16_ks2_kernel",
+_NO_SCRATCH = ["gemm_bf16_dma_kernelILi128ELb0ELi128", "gemm_bf16_dma_kernelILi128ELb1ELi128", "gemm_bf16_dma_kernelILi256", "gemm_bf16_hs_kernel", "gemm_bf16_ks2_kernel", "gemm_bf16_dma_n64_kernel",
                "gemm_kernelILi2ELi64", "gemm_kernelILi2ELi128", "gemm_tn_bf16_kernel", "gemm_tn_dma_kernelILi4", "gemm_tn_dma_kernelILi1", "attention_mfma_head_kernelILi7ELi8", "attention_mfma_head_kernelILi7ELi4",
                "attention_mfma_long_kernelILi64", "attention_mfma_kernelILi4", "conv0_ln_gelu_kernelItLi10", "layernorm_kernelIftLi2", "conv0_bwd_kernel",
                "fir_bank_kernel", "adam_multi_kernel"]
