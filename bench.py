@@ -235,7 +235,7 @@ def main():
             tnote = "profiles/r01_pmc_hbm.json (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE)"
         except (OSError, KeyError, ValueError):
             pass
-        roof = {"kernel": "bf16 GEMM (gemm_bf16_dma_kernel + its in-workgroup split-K form gemm_bf16_ks2_kernel: all front-end Linear/Conv1d launches of one step)", "bound": "mfma",
+        roof = {"kernel": "bf16 GEMM (gemm_bf16_dma_kernel, its in-workgroup split-K form gemm_bf16_ks2_kernel and the 128x64 form for the grouped conv: all front-end Linear/Conv1d launches of one step)", "bound": "mfma",
                 "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": tnote, "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(cfg, L_SAMPLES, bs) / max(n_launch, 1)),
                 "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / max(n_launch, 1), 2), "flops_per_step": fl}
