@@ -42,6 +42,21 @@ def test_linear_bf16_output_and_alpha():
     torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 48, 128), (128, 64, 64), (6368, 64, 8192), (1, 8, 64), (777, 20, 192), (12736, 1024, 4096), (6368, 512, 1024), (400, 1024, 512)])
+def test_bf16_dispatch_classes_narrow_and_under_filled(M, N, K):
+    """The default bf16 dispatch has three kernels: 128x64 tiles for N <= 64 (ragged N, clamped W rows), the in-workgroup split-K
+    form for launches of at most two tiles per CU with an even slab count >= 8, and the plain 128x128 kernel.  All of them with bias,
+    GELU and an f32 residual against an f64 reference of the bf16 operands."""
+    from occm_amd import ops
+    x, w = _r(M, K, seed=11).bfloat16(), _r(N, K, seed=12, scale=K ** -0.5).bfloat16()
+    b, r = _r(N, seed=13), _r(M, N, seed=14)
+    ref = (F.gelu(x.double() @ w.double().T + b.double()) + r.double()).float()
+    out = ops.linear(x.cuda(), w.cuda(), b.cuda(), act=ops.ACT_GELU, residual=r.cuda(), out_dtype=torch.float32)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=2e-3)
+    out2 = ops.linear(x.cuda(), w.cuda(), b.cuda(), act=ops.ACT_GELU, residual=r.cuda(), out_dtype=torch.float32)
+    assert torch.equal(out, out2)                                           # no atomics on these paths: run-to-run bit-identical
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("k,s,Tin", [(3, 2, 101), (2, 2, 64), (3, 2, 12799)])
 def test_conv1d_as_window_gemm(dt, k, s, Tin):
