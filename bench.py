@@ -1,47 +1,155 @@
 #!/usr/bin/env python3
 """Headline benchmark: utterances/s of one training step on 4 s @ 16 kHz synthetic utterances.
 
-Workload at N=1 = BASELINE.json configs[1]: XLS-R-300M frozen front-end (bf16 MFMA) + AASIST back-end
-(fwd + loss + bwd + Adam, f32), bs=32 per GPU.  N>1: weak scaling, 32 utterances per rank, one process per GPU
-(torchrun), RCCL all-reduce of the flat back-end gradient.  One JSON line on rank 0.
+Workload at N=1 = BASELINE.json configs[2], the largest single-GPU configuration: XLS-R-300M fine-tuned end to end (every
+parameter in the optimizer, as oc_training.py:324) + AASIST back-end, bs=64, RawBoost algo 5 on the GPU inside the step.
+N>1 = configs[3]: the same step on every rank (64 utterances per GPU, weak scaling), one process per GPU, per-layer RCCL
+all-reduce of the 1.26 GB flat gradient overlapped with backward.  `--frozen` runs configs[1] (frozen front-end, bs=32).
+One JSON line on rank 0.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8            # starts 8 ranks itself (torch.distributed.run) when WORLD_SIZE is not set
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-L_SAMPLES, BS = 64000, 32
+L_SAMPLES = 64000
+BS_FINETUNE, BS_FROZEN = 64, 32
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+GEMM_SOURCES = ("gemm.hip", "gemm_common.h", "gemm_tn.hip", "gemm_p8.hip")
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frozen", action="store_true", help="BASELINE configs[1] instead of the headline: XLS-R frozen (HIP-graph replay), bs 32, no RawBoost")
+    ap.add_argument("--finetune", nargs="?", const="full", default=None, choices=["full", "encoder"],
+                    help="full (default workload) = end-to-end as the reference's optimizer does; encoder = transformer only (not a BASELINE config)")
+    ap.add_argument("--bs", type=int, default=None, help="per-GPU batch (headline: 64; --frozen: 32)")
+    ap.add_argument("--rawboost", type=int, default=None, help="RawBoost algo 0-8 on the GPU inside the timed step (headline: 5; --frozen: 0)")
+    ap.add_argument("--xlsr", default="300m", choices=["300m", "1b"], help="1b: XLS-R-1B geometry (48 layers, d 1280, heads of 80), not the headline")
+    ap.add_argument("--backend", default="aasist", choices=["aasist", "senet"], help="senet: SE-ResNet34 on the XLS-R features (not the headline)")
+    ap.add_argument("--no-graph", action="store_true", help="--frozen only: do not replay the frozen front-end from a HIP graph")
+    ap.add_argument("--no-overlap", action="store_true", help="--frozen only: no side-stream prefetch of the next batch's features")
+    ap.add_argument("--dry-launch", action="store_true", help="rendezvous only (gloo, no GPU call): every rank reports world size and its shard of the "
+                    "utterance groups, rank 0 prints them as one JSON line")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------- launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """--gpus N without a torchrun environment: start N ranks as children (one per GPU) BEFORE this process touches a GPU, pass their
+    output through and exit with their status.  Replaces nn.DataParallel's single process (oc_training.py:328)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args):
+    """No GPU call: init_process_group over gloo, agree on the world size, shard the global batch's groups of 12."""
+    import torch.distributed as dist
+    from occm_amd import parallel
+    rank, world, local = parallel.init_from_env(backend="gloo")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, world))
+    n_groups = 2 * world                                   # 2 groups of 12 per rank in the rehearsal
+    lo, hi = parallel.shard_groups(n_groups, rank, world)
+    mine = {"rank": rank, "local_rank": local, "world": world, "groups": [lo, hi]}
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+    else:
+        seen = [mine]
+    ok = all(s["world"] == world for s in seen) and sorted(s["rank"] for s in seen) == list(range(world))
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks": seen, "n_groups": n_groups, "ok": ok}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ------------------------------------------------------------------------------------------------- workload arithmetic
 def synth_batch(B, rank, device):
+    import torch
     g = torch.Generator().manual_seed(1234 + rank)
     wav = (0.1 * torch.randn(B, L_SAMPLES, generator=g)).clamp(-1, 1)
     labels = (torch.arange(B) % 12 >= 6).long()              # [0]*6 + [1]*6 groups (oc_training.py:215-240)
     return wav.to(device), labels.to(device)
 
 
-def gemm_flops_per_utt(cfg, L):
-    """Algorithmic FLOPs of the launches of the bf16 GEMM kernel per utterance (SURVEY.md section 8d formula terms
-    FE (layers 1-6) + PROJ + POS + LIN); layer 0 of the conv stack and attention run in other kernels."""
+def conv_frames(L):
     Ts, Lc = [], L
     for k, s in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
         Lc = (Lc - k) // s + 1
         Ts.append(Lc)
+    return Ts
+
+
+def gemm_flops_per_utt(cfg, L):
+    """Algorithmic forward FLOPs of the bf16 GEMM launches per utterance (SURVEY.md section 8d formula terms FE (layers 1-6) + PROJ +
+    POS + LIN); layer 0 of the conv stack and attention run in other kernels.  Fine-tuning runs each of them three times
+    (forward, input gradient, weight gradient)."""
+    Ts = conv_frames(L)
     C, T, d, f, n = 512, Ts[-1], cfg.dim, cfg.ffn, cfg.layers
     fe = 2 * (sum(Ts[1:5]) * C * C * 3 + sum(Ts[5:7]) * C * C * 2)
     proj = 2 * T * C * d
     pos = 2 * (T + 1) * d * (d // cfg.pos_groups) * cfg.pos_k
     lin = 2 * T * (4 * d * d + 2 * d * f) * n
     return fe + proj + pos + lin
+
+
+def gemm_bytes_per_step(cfg, L, B, finetune):
+    """Algorithmic HBM bytes of the bf16 GEMM launches of one step: each launch reads its two operands once and writes its result
+    once (bf16 operands, bf16 or f32 results as the path stores them); fine-tuning adds the input-gradient and weight-gradient
+    launches (dY and W in, dX out; dY and X in, f32 dW accumulated = read + written)."""
+    Ts = conv_frames(L)
+    T, d, f, n = Ts[-1], cfg.dim, cfg.ffn, cfg.layers
+    M = B * T
+    shapes = []                                            # (rows, N, K, bytes of C per element)
+    for i in range(1, 7):
+        k = 3 if i < 5 else 2
+        shapes.append((B * Ts[i], 512, k * 512, 2))
+    shapes.append((M, d, 512, 2))
+    tot = 0
+    for (m, nn, kk, ce) in shapes:
+        tot += m * kk * 2 + nn * kk * 2 + m * nn * ce
+        if finetune:
+            tot += (m * nn * 2 + nn * kk * 2 + m * kk * 2) + (m * nn * 2 + m * kk * 2 + 2 * nn * kk * 4)
+    G, cg = cfg.pos_groups, d // cfg.pos_groups
+    pos_fwd = B * (T + cfg.pos_k) * d * 2 + d * cg * cfg.pos_k * 2 + M * d * 4 + M * d * 2
+    tot += pos_fwd
+    if finetune:
+        tot += pos_fwd + (M * d * 2 + B * (T + cfg.pos_k) * d * 2 + 2 * d * cg * cfg.pos_k * 4)
+    layer = [(M, 3 * d, d, 2, 0), (M, d, d, 4, 4), (M, f, d, 2, 0), (M, d, f, 4, 4)]     # (.., C bytes, residual bytes)
+    per = 0
+    for (m, nn, kk, ce, re) in layer:
+        per += m * kk * 2 + nn * kk * 2 + m * nn * (ce + re)
+        if finetune:
+            per += (m * nn * 2 + nn * kk * 2 + m * kk * 2) + (m * nn * 2 + m * kk * 2 + 2 * nn * kk * 4)
+    return tot + n * per
 
 
 def usable_cores():
@@ -67,29 +175,13 @@ def usable_cores():
     return max(1, n)
 
 
-def gemm_bytes_per_step(cfg, L, B):
-    """Algorithmic HBM bytes of the bf16 GEMM launches of one step: each launch reads A and W once and writes C once."""
-    Ts, Lc = [], L
-    for k, s in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
-        Lc = (Lc - k) // s + 1
-        Ts.append(Lc)
-    T, d, f, n = Ts[-1], cfg.dim, cfg.ffn, cfg.layers
-    M = B * T
-    tot = 0
-    for i in range(1, 7):
-        k = 3 if i < 5 else 2
-        tot += B * Ts[i - 1] * 512 * 2 + 512 * k * 512 * 2 + B * Ts[i] * 512 * 2
-    tot += M * 512 * 2 + d * 512 * 2 + M * d * 2                                   # post_extract_proj
-    tot += B * (T + cfg.pos_k) * d * 2 + d * (d // cfg.pos_groups) * cfg.pos_k * 2 + M * d * 4 + M * d * 2   # pos conv (+residual)
-    per_layer = (M * d * 2 + 3 * d * d * 2 + M * 3 * d * 2) + (M * d * 2 + d * d * 2 + 2 * M * d * 4) \
-        + (M * d * 2 + f * d * 2 + M * f * 2) + (M * f * 2 + d * f * 2 + 2 * M * d * 4)
-    return tot + n * per_layer
-
-
-def cpu_baseline(budget_s=25.0):
-    """The torch-CPU oracle (kind "port": the reference's fairseq front-end cannot run) on a bounded sample of the same
-    workload: frozen XLS-R-300M forward + AASIST fwd/bwd + Adam, bs=2, as many steps as fit the budget (>= 1)."""
-    from oracle import aasist_ref, losses_ref, xlsr_ref
+def cpu_baseline(finetune, rawboost, budget_s=25.0):
+    """The torch-CPU oracle (kind "port": the reference's fairseq front-end cannot run) on a bounded sample of the same step at bs=2:
+    (numpy RawBoost ->) XLS-R-300M (forward only when frozen, forward + backward when fine-tuned) -> AASIST fwd/bwd -> Adam over
+    every trained parameter; as many steps as fit the budget (>= 1)."""
+    import numpy as np
+    import torch
+    from oracle import aasist_ref, losses_ref, rawboost_np, xlsr_ref
     from oracle.fill import fill_like
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -97,14 +189,27 @@ def cpu_baseline(budget_s=25.0):
     px = fill_like(xlsr_ref.param_shapes(cfg), seed=0)
     pb = fill_like(aasist_ref.param_shapes(), seed=0)
     train = [v.requires_grad_(True) for k, v in pb.items() if v.dtype.is_floating_point and not k.split(".")[-1].startswith("running")]
+    if finetune:
+        train += [v.requires_grad_(True) for v in px.values()]
     opt = torch.optim.Adam(train, lr=1e-5)
     B = 2
     wav, labels = synth_batch(B, 0, "cpu")
+    rb_args = None
+    if rawboost:
+        from occm_amd.oc_training import rawboost_args
+        rb_args = rawboost_args()
+        np.random.seed(0)
     t0 = time.time()
     steps = 0
     while steps < 1 or (time.time() - t0) < budget_s * 0.6:
-        with torch.no_grad():
-            feats = xlsr_ref.extract_feat(wav, px, cfg)
+        x = wav
+        if rawboost:
+            x = torch.from_numpy(np.stack([rawboost_np.process_rawboost(w.numpy(), 16000, rb_args, rawboost) for w in wav]).astype(np.float32))
+        if finetune:
+            feats = xlsr_ref.extract_feat(x, px, cfg)
+        else:
+            with torch.no_grad():
+                feats = xlsr_ref.extract_feat(x, px, cfg)
         opt.zero_grad()
         emb, out = aasist_ref.backend_forward(feats, pb, train=True)
         loss = 0.0 * losses_ref.compactness_loss(emb) + 1.0 * losses_ref.descriptiveness_loss(out, labels)
@@ -112,85 +217,86 @@ def cpu_baseline(budget_s=25.0):
         opt.step()
         steps += 1
     dt = time.time() - t0
+    what = "XLS-R-300M %s + AASIST fwd/bwd + Adam%s" % ("fwd/bwd (fine-tuned)" if finetune else "frozen fwd", ", numpy RawBoost algo %d" % rawboost if rawboost else "")
     return {"value": round(B * steps / dt, 4), "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": "%d step(s) of bs=%d, fp32 torch-CPU oracle (XLS-R-300M frozen fwd + AASIST fwd/bwd + Adam), %d threads" % (steps, B, cores)}
+            "sample": "%d step(s) of bs=%d, fp32 torch-CPU oracle (%s), %d threads" % (steps, B, what, cores)}
 
 
+def gemm_source_sha():
+    h = hashlib.sha256()
+    for name in GEMM_SOURCES:
+        path = os.path.join(ROOT, "occm_amd", "csrc", name)
+        if os.path.exists(path):
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(tag):
+    """HBM bytes per GEMM launch from the committed PMC passes of THIS workload -- reported only when the profile was taken with the
+    GEMM sources of this tree (their hash is stored in the profile), otherwise null: a stale counter must not look like a measurement."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_%s.json" % tag)
+    try:
+        pm = json.load(open(path))
+        if pm.get("gemm_src_sha16") != gemm_source_sha():
+            return None, "profiles/%s is from other GEMM sources (%s): not reported" % (os.path.basename(path), pm.get("gemm_src_sha16"))
+        ks = [v for k, v in pm["kernels"].items() if "gemm_" in k and "bf16" in k or "gemm_p8" in k or "gemm_tn_dma" in k]
+        n = sum(v["launches"] for v in ks)
+        return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks) / max(n, 1)), \
+            "profiles/%s (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE, launch-weighted over the bf16 GEMM kernels)" % os.path.basename(path)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
+# ------------------------------------------------------------------------------------------------- main
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="do not replay the frozen front-end from a HIP graph")
-    ap.add_argument("--finetune", nargs="?", const="full", default=None, choices=["full", "encoder"],
-                    help="NOT the headline config: also train XLS-R (full = end-to-end as the reference's optimizer does, BASELINE configs[2] "
-                    "minus RawBoost; encoder = transformer only); prints the same JSON with a different workload name")
-    ap.add_argument("--bs", type=int, default=BS, help="per-GPU batch (headline: 32)")
-    ap.add_argument("--rawboost", type=int, default=0, help="RawBoost algo 1-8 applied on the GPU inside the timed step (configs[2]: 5)")
-    ap.add_argument("--xlsr", default="300m", choices=["300m", "1b"], help="NOT the headline config with 1b: XLS-R-1B geometry (48 layers, d 1280, heads of 80; "
-                    "BASELINE configs[4] asks for it in fp8 over 8 GPUs -- this runs it in bf16)")
-    ap.add_argument("--backend", default="aasist", choices=["aasist", "senet"], help="NOT the headline config with senet: SE-ResNet34 on the XLS-R "
-                    "features (models/senet.py ssl_resnet34, loss 0.1 c + 0.9 d as test_dataloader_v2.py:127)")
-    ap.add_argument("--no-overlap", action="store_true", help="do not compute the next batch's frozen-front-end features on a side stream "
-                    "while the back-end trains on the current one")
-    ap.add_argument("--split", type=int, default=1, help="run the front-end as this many concurrent sub-batches on separate HIP "
-                    "streams inside the graph; measured slower on MI355X (16.4 / 19.8 / 21.9 ms per step at 1 / 2 / 4), kept for experiments")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_launch:
+        sys.exit(dry_launch(args))
 
-    from occm_amd import ops, parallel
+    import torch
+    from occm_amd import backend_ops, ops, parallel
     from occm_amd._lib import require_gpu
     from occm_amd.models import xlsr
     from occm_amd.models.sslassist import AModel
     from occm_amd.trainer import OcTrainer
     require_gpu()
     rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, world))
     local = local % max(1, torch.cuda.device_count())       # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = xlsr.XlsrConfig.xlsr_300m() if args.xlsr == "300m" else xlsr.XlsrConfig.xlsr_1b()
-    bs = args.bs
+    finetune = False if args.frozen else (args.finetune or "full")
+    bs = args.bs if args.bs is not None else (BS_FROZEN if args.frozen else BS_FINETUNE)
+    rawboost = args.rawboost if args.rawboost is not None else (0 if args.frozen else 5)
     if args.backend == "senet":
         from occm_amd.models.senet import ssl_resnet34
-        model = ssl_resnet34(dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, finetune_ssl=args.finetune or False)
+        model = ssl_resnet34(dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, finetune_ssl=finetune, synthetic_ssl=True)
         wc, wd = 0.1, 0.9
     else:
-        model = AModel(None, dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, seed=0, finetune_ssl=args.finetune or False)
+        model = AModel(None, dev, ssl_cfg=cfg, ssl_dtype=torch.bfloat16, seed=0, finetune_ssl=finetune, synthetic_ssl=True)
         wc, wd = 0.0, 1.0
     model.train()
-    trainer = OcTrainer(model, lr=1e-5, w_compact=wc, w_descr=wd, train_frontend=bool(args.finetune), rawboost_algo=args.rawboost, group_size=12 if bs % 12 == 0 else None)
+    trainer = OcTrainer(model, lr=1e-5, w_compact=wc, w_descr=wd, train_frontend=bool(finetune), rawboost_algo=rawboost,
+                        group_size=12 if bs % 12 == 0 else None, rank=rank)
     wav, labels = synth_batch(bs, rank, dev)
     fe = model.ssl_model.model
-    if args.finetune:
-        args.no_graph = True
 
-    # The frozen front-end is a fixed launch sequence: capture it once into a HIP graph (launch-bound otherwise).
+    # configs[1]: the frozen front-end is a fixed launch sequence: capture it once into a HIP graph (launch-bound otherwise).
     graph = None
-    if not args.no_graph:
+    if not finetune and not args.no_graph:
         static_wav = wav.clone()
         orig_forward = fe.forward
-        nsplit = max(1, args.split)
-        T = xlsr.n_frames(L_SAMPLES)
-        static_feats = torch.empty(bs, T, cfg.dim, device=dev, dtype=torch.float32)
-        cuts = [bs * i // nsplit for i in range(nsplit + 1)]
-        side = [torch.cuda.Stream(device=dev) for _ in range(nsplit - 1)]
-
-        def split_forward():
-            main = torch.cuda.current_stream()
-            for i in range(nsplit):
-                st = main if i == 0 else side[i - 1]
-                if st is not main:
-                    st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    orig_forward(static_wav[cuts[i]:cuts[i + 1]], out_dtype=torch.float32, slot=i, out=static_feats[cuts[i]:cuts[i + 1]])
-            for st in side:
-                main.wait_stream(st)
-        split_forward()
+        static_feats = torch.empty(bs, xlsr.n_frames(L_SAMPLES), cfg.dim, device=dev, dtype=torch.float32)
+        orig_forward(static_wav, out_dtype=torch.float32, out=static_feats)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         # thread_local: with world > 1 the RCCL watchdog thread polls events while this thread captures
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            split_forward()
+            orig_forward(static_wav, out_dtype=torch.float32, out=static_feats)
 
         def replay_forward(w, out_dtype=None, taps=None):
             static_wav.copy_(w)
@@ -201,7 +307,7 @@ def main():
     # Every step does the whole path on one batch.  With the frozen front-end the trainer software-pipelines two steps: the data
     # stage (RawBoost + XLS-R features) of step i+1 runs on a side stream while the back-end of step i trains; the timed region
     # still contains exactly `steps` data stages and `steps` back-end updates (the first data stage is not overlapped).
-    overlap = not args.no_overlap and not args.finetune
+    overlap = not args.no_overlap and not finetune
     for i in range(args.warmup):
         trainer.step(wav, labels, next_wav=wav if overlap and i + 1 < args.warmup else None)
     parallel.barrier(); torch.cuda.synchronize()
@@ -213,49 +319,61 @@ def main():
     lc, ld = trainer.last
     loss_d = float(ld.item())
 
-    # ---- roofline of the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / measured launch time ----
+    # ---- roofline of the dominant kernel family (bf16 MFMA GEMM): algorithmic FLOPs / launch time measured with HIP events on the
+    # launch stream, in extra untimed steps of the same workload ----
     roof = None
-    if rank == 0 and not args.finetune:
+    if rank == 0:
+        nprof = 2
         if graph is not None:
             fe.forward = orig_forward
         ops.PROFILE = []
-        for _ in range(3):
-            fe.forward(wav, out_dtype=torch.float32)
+        if finetune:
+            for _ in range(nprof):
+                trainer.step(wav, labels)
+        else:
+            for _ in range(nprof):
+                fe.forward(wav, out_dtype=torch.float32)
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
-        t_ms = sum(a.elapsed_time(b) for kind, a, b in recs if kind == "gemm_bf16") / 3.0
-        n_launch = sum(1 for kind, _, _ in recs if kind == "gemm_bf16") // 3
-        fl = gemm_flops_per_utt(cfg, L_SAMPLES) * bs
+        sel = [(a, b) for kind, a, b in recs if kind == "gemm_bf16"]
+        t_ms = sum(a.elapsed_time(b) for a, b in sel) / nprof
+        n_launch = len(sel) // nprof
+        fl = gemm_flops_per_utt(cfg, L_SAMPLES) * bs * (3 if finetune == "full" else 1)
+        if finetune == "encoder":
+            Ts = conv_frames(L_SAMPLES)
+            fl = gemm_flops_per_utt(cfg, L_SAMPLES) * bs + 2 * (2 * Ts[-1] * (4 * cfg.dim ** 2 + 2 * cfg.dim * cfg.ffn) * cfg.layers) * bs
         ach = fl / (t_ms * 1e-3) / 1e12
-        traffic, tnote = None, None
-        try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
-            ks = [v for k, v in pm["kernels"].items() if "gemm_bf16_" in k]          # the bf16 GEMM family (default + half-slab kernels)
-            traffic = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks))
-            tnote = "profiles/r01_pmc_hbm.json (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE)"
-        except (OSError, KeyError, ValueError):
-            pass
-        roof = {"kernel": "bf16 GEMM (gemm_bf16_dma_kernel, its in-workgroup split-K form gemm_bf16_ks2_kernel and the 128x64 form for the grouped conv: all front-end Linear/Conv1d launches of one step)", "bound": "mfma",
-                "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": tnote, "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(cfg, L_SAMPLES, bs) / max(n_launch, 1)),
-                "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / max(n_launch, 1), 2), "flops_per_step": fl}
+        traffic, tnote = pmc_traffic("frozen" if not finetune else "finetune")
+        roof = {"kernel": "bf16 MFMA GEMM family: every Linear / Conv1d launch of the XLS-R front-end" +
+                (" -- forward, input gradient (occ_gemm) and weight gradient (occ_gemm_tn)" if finetune else " (occ_gemm)"),
+                "bound": "mfma", "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
+                "traffic": traffic, "traffic_source": tnote,
+                "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(cfg, L_SAMPLES, bs, finetune == "full") / max(n_launch, 1)),
+                "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / max(n_launch, 1), 2), "flops_per_step": fl,
+                "gemm_ms_per_step": round(t_ms, 3)}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(bool(finetune), rawboost)
     if rank == 0:
-        if args.backend == "senet":
-            wl = "XLSR-%s %s frontend + SE-ResNet34 backend, bs=%d per GPU (not a BASELINE config; models/senet.py ssl_resnet34)" % (args.xlsr.upper(), "fine-tuned" if args.finetune else "frozen", bs)
-        else:
-            wl = ("XLSR-300M frozen frontend + AASIST backend, bs=%d per GPU, 64000-sample utterances (BASELINE configs[1])" % bs) if not args.finetune else \
-            ("XLSR-300M fine-tuned (%s) + AASIST backend, bs=%d per GPU (BASELINE configs[2]%s)" % (args.finetune, bs, ", RawBoost algo %d on-GPU" % args.rawboost if args.rawboost else " without RawBoost"))
+        cfgno = "configs[1]" if not finetune else ("configs[2]" if world == 1 else "configs[3]")
+        std = args.backend == "aasist" and args.xlsr == "300m" and finetune in (False, "full") and bs == (BS_FINETUNE if finetune else BS_FROZEN) and \
+            rawboost == (5 if finetune else 0)
+        wl = "XLSR-%s %s + %s backend, bs=%d per GPU, 64000-sample utterances%s (%s)" % (
+            args.xlsr.upper(), ("fine-tuned end to end" if finetune == "full" else "fine-tuned (encoder only)") if finetune else "frozen frontend",
+            "AASIST" if args.backend == "aasist" else "SE-ResNet34", bs, ", RawBoost algo %d on-GPU" % rawboost if rawboost else "",
+            "BASELINE %s" % cfgno if std else "not a BASELINE config")
         out = {"metric": "utterances/sec (4 s @16 kHz) training step", "value": round(bs * world * args.steps / dt, 2), "unit": "utterances/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": wl,
-                          "global_batch": bs * world, "samples_per_utt": L_SAMPLES, "parallelism": "dp%d" % world,
-                          "frontend": "bf16 MFMA, f32 accumulate, HIP-graph replay" + (", features of step i+1 computed on a side stream during step i's back-end" if overlap else ""), "backend": ("fwd+bwd, f32 storage, bf16-MFMA GEMMs and weight gradients (f32 accumulate), dropout on, Adam lr=1e-5" if args.backend == "aasist"
+               "config": {"workload": wl, "global_batch": bs * world, "samples_per_utt": L_SAMPLES, "parallelism": "dp%d" % world,
+                          "frontend": ("bf16 MFMA fwd + bwd, f32 accumulate, f32 master weights and gradients, Adam over all 315.4 M parameters" if finetune == "full" else
+                                       "bf16 MFMA, f32 accumulate" + (", HIP-graph replay" if graph is not None else "") +
+                                       (", features of step i+1 computed on a side stream during step i's back-end" if overlap else "")),
+                          "backend": ("fwd+bwd, f32 storage, bf16-MFMA GEMMs and weight gradients (f32 accumulate), dropout on, Adam lr=1e-5" if args.backend == "aasist"
                                       else "SE-ResNet34 fwd+bwd, f32 storage, bf16-MFMA convolutions and weight gradients (f32 accumulate), Adam lr=1e-5"),
-                          "loss": "%.1f*compactness + %.1f*descriptiveness (%s)" % (wc, wd, "oc_training.py:380-381" if args.backend == "aasist" else "test_dataloader_v2.py:127"), "final_loss_d": round(loss_d, 5)},
+                          "gradient_exchange": "none (1 rank)" if world == 1 else "RCCL all-reduce of the flat f32 gradients, per transformer layer, overlapped with backward",
+                          "loss": "%.1f*compactness + %.1f*descriptiveness (%s)" % (wc, wd, "oc_training.py:380-381" if args.backend == "aasist" else "test_dataloader_v2.py:127"),
+                          "final_loss_d": round(loss_d, 5), "gemm_src_sha16": gemm_source_sha()},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:

@@ -145,6 +145,11 @@ typedef struct occ_gemm_tn_desc {
     void* colsum;                      /* optional f32 [N1]: += alpha * column sums of A (the bias gradient), or NULL */
     int a_dtype, b_dtype;              /* OCC_F32 (0, default) or OCC_BF16: operand storage; products and sums are f32 either way */
     int compute;                       /* OCC_F32 (0, default): exact-f32 MFMA; OCC_BF16: operands rounded to bf16, bf16 MFMA, f32 accumulate */
+    /* Optional caller-owned device scratch (16-byte aligned) for the large bf16 products: the reduction over M is cut into pieces
+     * over workgroups and the pieces meet in f32 slabs here instead of float atomics on C.  Its contents are undefined between calls;
+     * calls that share one workspace must be ordered on one stream.  NULL / 0: the atomics path is used.  268 MB covers every
+     * weight of XLS-R-300M/1B at any batch size (256 workgroups x 256 KiB slabs + tickets).                                        */
+    void* workspace; int64_t workspace_bytes;
 } occ_gemm_tn_desc;
 int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream);
 /* out[n] += alpha * sum_m A[m,n] (bias gradients).                                                   */

@@ -40,7 +40,8 @@ class GemmTnDesc(ctypes.Structure):
                 ("B", ctypes.c_void_p), ("b_map", RowMap), ("b_nseg", ctypes.c_int64), ("b_seg_len", ctypes.c_int64),
                 ("b_seg_stride", ctypes.c_int64),
                 ("C", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("alpha", ctypes.c_float), ("colsum", ctypes.c_void_p),
-                ("a_dtype", ctypes.c_int), ("b_dtype", ctypes.c_int), ("compute", ctypes.c_int)]
+                ("a_dtype", ctypes.c_int), ("b_dtype", ctypes.c_int), ("compute", ctypes.c_int),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64)]
 
 
 _P = ctypes.c_void_p

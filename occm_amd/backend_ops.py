@@ -30,8 +30,23 @@ def full(rows, C):
     return RowMap(int(rows), 0, int(C), 0, 0)
 
 
+_TN_WS = {}
+TN_WORKSPACE_BYTES = 256 * 262144 + 4096        # one 256 KiB slab per CU + the ticket block
+
+
+def tn_workspace():
+    """Device scratch of occ_gemm_tn's large bf16 products, one per (device, stream): calls sharing it must be ordered on that stream."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    if key not in _TN_WS:
+        _TN_WS[key] = torch.empty(TN_WORKSPACE_BYTES, device="cuda", dtype=torch.uint8)
+    return _TN_WS[key]
+
+
 def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsum_out=None, a_bf16=False, b_bf16=False, bf16_mfma=False):
     d = GemmTnDesc()
+    if a_bf16 and b_bf16 and bf16_mfma and N1 % 256 == 0 and N2 % 256 == 0 and M >= 1024:
+        ws = tn_workspace()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     d.M, d.N1, d.N2 = int(M), int(N1), int(N2)
     d.A, d.a_map = _ai(A), a_map
     d.B, d.b_map = _ai(Bm), b_map
@@ -43,6 +58,14 @@ def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsu
     d.colsum = _ai(colsum_out)
     d.a_dtype, d.b_dtype = int(bool(a_bf16)), int(bool(b_bf16))
     d.compute = 1 if bf16_mfma else 0          # OCC_BF16 / OCC_F32
+    from . import ops
+    if ops.PROFILE is not None:                # bench.py: time this launch with events on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().occ_gemm_tn(ctypes.byref(d), stream_ptr()), "occ_gemm_tn")
+        e1.record()
+        ops.PROFILE.append(("gemm_bf16" if (a_bf16 and b_bf16 and bf16_mfma) else "gemm_tn_other", e0, e1))
+        return
     check(lib().occ_gemm_tn(ctypes.byref(d), stream_ptr()), "occ_gemm_tn")
 
 

@@ -696,6 +696,29 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     // the 128x128 tile's finer granularity wins by 3-15 % (scripts/bench_gemm.py), so it stays the default there.
     const bool big = d->M >= 4096 && d->N >= 4096 && d->M % 256 == 0;
     int fam = -100;
+    const bool p8_ok = d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && nseg == 1 && ng == 1 && d->N >= 256 && d->M >= 256;
+    // Default for well-filled bf16 launches: the 256x256 eight-phase kernel (gemm_p8.hip).  Measured at M = 12736 (bs 64) against the
+    // 128x128 kernels below: fc2 1105 vs 838 TFLOP/s, out-proj 760 vs 633, conv1 1084 vs 881, 4096^3 1248 vs 1058; a launch with fewer
+    // than ~0.7 tiles per CU (fc2 at M = 6368: 100 tiles) keeps the small-tile kernels.  OCC_GEMM_P8=0 switches it off.
+    static const int p8_env = getenv("OCC_GEMM_P8") ? atoi(getenv("OCC_GEMM_P8")) : 1;
+    const long long p8_tiles = occ_cdiv(d->M, 256) * occ_cdiv(d->N, 256);
+    const bool x_fits_32bit = true;            // DMA offsets are 32-bit byte offsets from the operand base (checked below)
+    if (p8_ok && (variant == 30 || (variant == 1 && p8_env && p8_tiles * 10 >= 7ll * cu_count())) && x_fits_32bit) {
+        // largest byte offset the kernel forms: last row of A through its row map, last row of W
+        const long long last_a = ((d->M - 1) / d->a_map.rows_per_batch) * d->a_map.batch_stride +
+                                 (d->a_map.rows_per_line > 0 ? (d->a_map.rows_per_batch / d->a_map.rows_per_line + 1) * d->a_map.line_stride + d->a_map.rows_per_line * d->a_map.row_stride
+                                                             : d->a_map.rows_per_batch * d->a_map.row_stride);
+        if ((last_a + d->K) * 2 < (1ll << 32) && (d->N * d->ldw) * 2 < (1ll << 32)) {
+            gemm_p8_launch(a, s);
+            OCC_LAUNCH_CHECK("occ_gemm");
+            return OCC_OK;
+        }
+    }
+    if (false) {
+        gemm_p8_launch(a, s);
+        OCC_LAUNCH_CHECK("occ_gemm");
+        return OCC_OK;
+    }
     if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant != 1 && variant != 3 && variant != 4 && variant != 14 && variant != 19 && variant != 22) {
         fam = gemm_family_launch(variant, a, d, ng, s);          // experimental kernels live in gemm_family.hip
         if (fam != -100 && fam != OCC_OK) return fam;

@@ -47,7 +47,9 @@ __device__ __forceinline__ float act_rt(int act, float v) {
 // once per 16-column block instead of once per 16x16 block.  The generic gemm_epilogue below handles every other combination
 // with run-time switches; on the 128x128 tile that code executed ~1500 instructions per thread, which (with the workgroups of a
 // round reaching it together) was a third of a K = 1024 GEMM's run time.
-template <int NJ, bool HASB, bool GELU, bool HASR, bool CBF>
+// AUXM: 0 no side tensor; 1 store the bf16 pre-activation (acc + bias) to aux (forward of fc1, kept for backward); 2 multiply by
+// GELU'(aux) (the input gradient through fc1's activation).
+template <int NJ, bool HASB, bool GELU, bool HASR, bool CBF, int AUXM = 0>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
                                                    const f32x4* breg, long long mlim) {
     f32x4 bv[4];
@@ -71,6 +73,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
             if (n >= a.N) continue;
             f32x4 v = acc[i][j];
             if (HASB) v += bv[i];
+            if (AUXM == 1) {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2*>(a.aux + coff + n) = o;
+            }
+            if (AUXM == 2) {
+                const uint2 u = *reinterpret_cast<const uint2*>(a.aux + coff + n);
+                v[0] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x & 0xffff))); v[1] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x >> 16)));
+                v[2] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y & 0xffff))); v[3] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y >> 16)));
+            }
             if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
             if (HASR) v += *reinterpret_cast<const f32x4*>(a.R + (roff + n) * 4);
             if (CBF) {
@@ -112,6 +125,11 @@ template <int NJ>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
                                               const f32x4* breg = nullptr, long long mlim_in = -1) {
     const long long mlim = mlim_in >= 0 ? mlim_in : a.M;        // rows this call may store: a short tile stops at its own end
+    // the two side-tensor forms of the fine-tuning step (fc1 forward keeps its pre-activation; fc2's input gradient goes through GELU')
+    if (a.alpha == 1.0f && a.aux && !a.R && a.c_dtype != OCC_F32) {
+        if (a.act == OCC_ACT_GELU && a.bias) { gemm_epilogue_fast<NJ, true, true, false, true, 1>(a, acc, mrow0, ncol0, fr, fq, cshift, breg, mlim); return; }
+        if (a.act == OCC_ACT_GELU_GRAD && !a.bias) { gemm_epilogue_fast<NJ, false, false, false, true, 2>(a, acc, mrow0, ncol0, fr, fq, cshift, breg, mlim); return; }
+    }
     if (a.alpha == 1.0f && !a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU) && (!a.R || a.r_dtype == OCC_F32)) {
         // wave-uniform flags -> one scalar branch chain into a straight-line instantiation
         const int key = (a.bias ? 8 : 0) | (a.act == OCC_ACT_GELU ? 4 : 0) | (a.R ? 2 : 0) | (a.c_dtype != OCC_F32 ? 1 : 0);
@@ -214,6 +232,9 @@ inline int cu_count() {
     return n;
 }
 
+
+// 256x256 eight-phase kernel (gemm_p8.hip); the caller has checked: bf16 operands, K % 64 == 0, one K segment, one group
+void gemm_p8_launch(GemmArgs& a, hipStream_t s);
 
 // experimental kernels (gemm_family.hip); returns -100 when `variant` is not one of them, else OCC_OK / an error status
 int gemm_family_launch(int variant, GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_t s);

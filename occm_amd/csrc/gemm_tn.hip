@@ -27,6 +27,7 @@ struct TnArgs {
     int atomic;               // gemm_tn_dma_kernel: several row splits add into C -> atomics; one split: plain read-modify-write
     int t1, t2;               // tiles along N1 / N2 (grid is 1-D: XCD-aware order, see tn_block)
     float* colsum;            // optional: colsum[n1] += alpha * sum_m A[m, n1] (bias gradient), done by the n2-tile-0 workgroups
+    long long m_first;        // gemm_tn_dma_kernel: first reduction row of this launch (the rows before it were done by gemm_tn_p8)
 };
 
 __device__ __forceinline__ float4 ld4_bf16(const unsigned short* p) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(4, 4))
     __shared__ uint4 lds_all[KG * 2 * SLD * 16];          // per group: A slab (64 rows x 16 chunks), then B slab
     int bx, by, bz; tn_block(a, bx, by, bz);
     const long long n1_0 = (long long)bx * TD, n2_0 = (long long)by * TD;
-    const long long wg_begin = (long long)bz * a.rows_per_split;
+    const long long wg_begin = a.m_first + (long long)bz * a.rows_per_split;
     const long long wg_end = wg_begin + a.rows_per_split < a.M ? wg_begin + a.rows_per_split : a.M;
     const int kg = KG > 1 ? threadIdx.x >> 8 : 0;
     // every group runs the same number of slabs (the barriers are workgroup-wide); a group whose rows are used up stages zeros
@@ -455,6 +456,17 @@ static void launch_colsum_bf16_vec(const unsigned short* A, const RowMapI& amap,
 
 }  // namespace
 
+// gemm_tn_p8.hip
+int occ_tn_p8_try(long long M, long long N1, long long N2, const void* A, const RowMapI& amap, const void* B, const RowMapI& bmap, float* C, long long ldc,
+                  float alpha, void* workspace, long long workspace_bytes, long long max_a_off, long long max_b_off, hipStream_t s);
+
+static long long max_row_off(const occ_rowmap& m, long long M) {       // upper bound of the element offset of any row < M
+    const long long nb = (M - 1) / m.rows_per_batch;
+    long long in_batch = m.rows_per_line > 0 ? (m.rows_per_batch / m.rows_per_line + 1) * m.line_stride + m.rows_per_line * m.row_stride : m.rows_per_batch * m.row_stride;
+    if (in_batch < 0) in_batch = 0;
+    return nb * (m.batch_stride > 0 ? m.batch_stride : 0) + in_batch;
+}
+
 extern "C" {
 
 int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
@@ -473,13 +485,31 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
     a.M = d->M; a.N1 = d->N1; a.N2 = d->N2;
     a.A = d->A; a.amap = to_rowmap(d->a_map);
     a.B = d->B; a.bmap = to_rowmap(d->b_map); a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->b_seg_stride;
-    a.C = (float*)d->C; a.ldc = d->ldc; a.alpha = d->alpha; a.colsum = (float*)d->colsum; a.atomic = 1;
+    a.C = (float*)d->C; a.ldc = d->ldc; a.alpha = d->alpha; a.colsum = (float*)d->colsum; a.atomic = 1; a.m_first = 0;
     const bool abf0 = d->a_dtype == OCC_BF16, bbf0 = d->b_dtype == OCC_BF16;
     static const int dma_env = getenv("OCC_TN_DMA") ? atoi(getenv("OCC_TN_DMA")) : 1;
     if (dma_env && d->compute == OCC_BF16 && abf0 && bbf0 && d->N1 % 8 == 0 && d->N2 % 8 == 0 && d->N1 >= 128 && d->N2 >= 128 && d->M >= 256 &&
         (nseg == 1 || seg_len % TD == 0) && d->ldc % 4 == 0 && ((uintptr_t)d->C & 15) == 0 &&
         d->a_map.row_stride % 8 == 0 && d->a_map.batch_stride % 8 == 0 && d->a_map.line_stride % 8 == 0 &&
         d->b_map.row_stride % 8 == 0 && d->b_map.batch_stride % 8 == 0 && d->b_map.line_stride % 8 == 0 && (nseg == 1 || d->b_seg_stride % 8 == 0)) {
+        // Large outputs (multiples of 256 both ways, one K segment): the 256x256 eight-phase kernel on all whole 64-row K-tiles, reduction
+        // pieces joined through workspace slabs instead of atomics; what is left (M % 64 rows) goes through the kernel below.
+        if (nseg == 1) {
+            const long long rows64 = d->M - d->M % 64;
+            const int r = occ_tn_p8_try(rows64, d->N1, d->N2, d->A, a.amap, d->B, a.bmap, a.C, a.ldc, a.alpha, d->workspace, d->workspace_bytes,
+                                        max_row_off(d->a_map, d->M) + d->N1, max_row_off(d->b_map, d->M) + d->N2, (hipStream_t)stream);
+            if (r < 0) { occ_set_error("occ_gemm_tn: workspace memset failed"); return OCC_ELAUNCH; }
+            if (r == 1) {
+                if (a.colsum) launch_colsum_bf16_vec((const unsigned short*)a.A, a.amap, a.M, a.N1, a.colsum, a.alpha, (hipStream_t)stream);
+                if (rows64 < d->M) {
+                    a.m_first = rows64; a.rows_per_split = SLD; a.atomic = 0;
+                    a.t1 = (int)occ_cdiv(d->N1, TD); a.t2 = (int)occ_cdiv(d->N2, TD);
+                    hipLaunchKernelGGL(gemm_tn_dma_kernel<1>, dim3((unsigned)(a.t1 * a.t2)), dim3(THREADS), 0, (hipStream_t)stream, a);
+                }
+                OCC_LAUNCH_CHECK("occ_gemm_tn");
+                return OCC_OK;
+            }
+        }
         const long long u1 = occ_cdiv(d->N1, TD), u2 = occ_cdiv(d->N2, TD);
         // KG groups of four waves split the rows inside a workgroup (no atomics between them); workgroups beyond one per tile split the
         // rows further and do need atomics, so there are only as many as it takes to have ~one 16-wave workgroup per CU

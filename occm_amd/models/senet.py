@@ -497,10 +497,11 @@ class ssl_resnet34(torch.nn.Module):
     """senet.py:162-185: XLS-R features [B,T,1024] -> unsqueeze(1) -> SE-ResNet34."""
 
     def __init__(self, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, state_dict=None, finetune_ssl=False, seed=1,
-                 backend_compute=None):
+                 backend_compute=None, ssl_cp_path=None, synthetic_ssl=False):
         super().__init__()
         from .xlsr import SSLModel
-        self.frontend = SSLModel(device, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, finetune=finetune_ssl)
+        self.frontend = SSLModel(device, cp_path=ssl_cp_path, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, finetune=finetune_ssl,
+                                 synthetic=synthetic_ssl)
         if backend_compute is None:         # same rule as AModel: a bf16 front-end brings the bf16-MFMA back-end mode
             backend_compute = "bf16" if ssl_dtype == torch.bfloat16 else "f32"
         self.resnet34 = se_resnet34(state_dict=state_dict, device=device, seed=seed, compute=backend_compute)
@@ -516,15 +517,15 @@ class ssl_resnet34(torch.nn.Module):
     def state_dict(self, *a, **kw):
         """Keys as the reference module tree gives them (senet.py:165-166): ``resnet34.*`` and ``frontend.model.*`` (fairseq names)."""
         sd = {"resnet34." + k: v for k, v in self.resnet34.state_dict().items()}
-        ssl = dict(self.frontend._params)
-        if getattr(self.frontend, "finetune", False):
-            ssl.update(self.frontend.model.export_params())
-        for k, v in ssl.items():
+        for k, v in self.frontend.full_state_dict().items():
             sd["frontend.model." + k] = v.detach().clone() if torch.is_tensor(v) else v
         return sd
 
     def load_state_dict(self, sd, strict=True):
         self.resnet34.load_state_dict({k[len("resnet34."):]: v for k, v in sd.items() if k.startswith("resnet34.")})
+        ssl = {k[len("frontend.model."):]: v for k, v in sd.items() if k.startswith("frontend.model.")}
+        if ssl or strict:
+            self.frontend.load_params(ssl, strict=strict)
         return self
 
 

@@ -145,7 +145,7 @@ class AasistBackend:
         self.ctx = None
         self.rng_seed = seed
         self.rng_step = 0
-        self.load_reference_params(params if params is not None else synthetic_backend_params(seed))
+        self.load_reference_params(params if params is not None else synthetic_backend_params(seed), strict_buffers=False)
 
     def _view(self, flat, key):
         off, shp = self.slots[key]
@@ -155,11 +155,14 @@ class AasistBackend:
         return flat[off:off + n].view(shp)
 
     # ---------------------------------------------------------------- checkpoint layout <-> internal --
-    def load_reference_params(self, sd):
+    def load_reference_params(self, sd, strict=True, strict_buffers=None):
+        strict_buffers = strict if strict_buffers is None else strict_buffers      # running statistics: a fresh model starts from the defaults
         sd = {k: v for k, v in sd.items() if not k.startswith("ssl_model.")}
         with torch.no_grad():
             for name, shp in self.table:
                 if name not in sd:
+                    if not strict:
+                        continue
                     raise OccError("AASIST state_dict lacks %s" % name)
                 v = sd[name].detach().to(self.device, torch.float32)
                 if tuple(v.shape) != tuple(shp):
@@ -176,6 +179,8 @@ class AasistBackend:
             for k in self.buf:
                 if k in sd:
                     self.buf[k].copy_(sd[k].to(self.device).reshape(self.buf[k].shape))
+                elif strict_buffers:
+                    raise OccError("AASIST state_dict lacks buffer %s" % k)
 
     def state_dict(self):
         out = {}
@@ -676,10 +681,11 @@ class AModel(torch.nn.Module):
     deterministic synthetic filler because no checkpoint exists offline (the reference hard-codes a path, :24)."""
 
     def __init__(self, args=None, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, backend_state_dict=None, seed=0,
-                 backend_compute=None, finetune_ssl=False):
+                 backend_compute=None, finetune_ssl=False, ssl_cp_path=None, synthetic_ssl=False, ssl_train_cfg=None):
         super().__init__()
         self.device = device
-        self.ssl_model = SSLModel(device, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, seed=seed, finetune=finetune_ssl)
+        self.ssl_model = SSLModel(device, cp_path=ssl_cp_path, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, seed=seed, finetune=finetune_ssl,
+                                  synthetic=synthetic_ssl, train_cfg=ssl_train_cfg)
         if backend_compute is None:
             backend_compute = "bf16" if ssl_dtype == torch.bfloat16 else "f32"
         self.backend = AasistBackend(backend_state_dict, device=device, seed=seed, compute=backend_compute)
@@ -693,20 +699,19 @@ class AModel(torch.nn.Module):
         return self.backend.backward(demb, dlogits)
 
     def state_dict(self, *a, **kw):
+        """Reference key set (oc_training.py:401 saves ``aasist.module.state_dict()``): the back-end's 247 keys plus EVERY
+        ``ssl_model.model.*`` tensor of the loaded fairseq checkpoint -- also the ones the features_only forward never reads --
+        so the reference's strict ``load_state_dict`` (oc_classifier.py:340) accepts the file."""
         sd = self.backend.state_dict()
-        ssl = dict(self.ssl_model._params)
-        if getattr(self.ssl_model, "finetune", False):
-            ssl.update(self.ssl_model.model.export_params())        # trained encoder tensors, fairseq names
-        for k, v in ssl.items():
-            sd["ssl_model.model." + k] = v
+        for k, v in self.ssl_model.full_state_dict().items():
+            sd["ssl_model.model." + k] = v.detach().clone() if torch.is_tensor(v) else v
         return sd
 
     def load_state_dict(self, sd, strict=True):
-        self.backend.load_reference_params(sd)
+        """strict (the reference's default): every back-end key and every ``ssl_model.model.*`` tensor of the path must be present
+        with the right shape -- a checkpoint can never leave random tensors in place silently."""
+        self.backend.load_reference_params(sd, strict=strict)
         ssl = {k[len("ssl_model.model."):]: v for k, v in sd.items() if k.startswith("ssl_model.model.")}
-        if ssl:
-            self.ssl_model._params.update({k: v for k, v in ssl.items() if k in self.ssl_model._params})
-            self.ssl_model.model.pack(self.ssl_model._params)
-        elif strict and any(k.startswith("ssl_model.") for k in sd):
-            raise OccError("unrecognised ssl_model.* keys")
+        if ssl or strict:
+            self.ssl_model.load_params(ssl, strict=strict)
         return self

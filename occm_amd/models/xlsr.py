@@ -212,31 +212,45 @@ class XlsrFrontend:
 
 class SSLModel(torch.nn.Module):
     """Mirror of models/xlsr.py:25-52 (and sslassist.py:20-49): ``SSLModel(device)``, ``.out_dim``,
-    ``.extract_feat(x)``.  The reference hard-codes a fairseq checkpoint path (xlsr.py:29); here the
-    weights come from ``state_dict`` (fairseq names), a ``cp_path`` torch file holding them, or -- when
-    neither is given -- the deterministic synthetic filler (no checkpoint can exist offline)."""
+    ``.extract_feat(x)``.  The reference hard-codes a fairseq checkpoint path (xlsr.py:29) and fails when the file is absent;
+    here the weights come from ``state_dict`` (fairseq names) or a ``cp_path`` torch file holding them (a fairseq-shaped
+    ``{"model": ..., "cfg": ...}`` file or a bare state dict) and a missing checkpoint is an error too.  ``synthetic=True`` is the
+    explicit opt-in (tests, bench.py: no checkpoint can exist offline) to the deterministic filler.
 
-    def __init__(self, device="cuda", cp_path=None, state_dict=None, cfg=None, dtype=torch.bfloat16, seed=0, finetune=False):
+    Tensors of the checkpoint that the features_only forward never touches (``mask_emb``, ``quantizer.*``, ``project_q.*``,
+    ``final_proj.*`` ...) are kept in ``extra_state`` and re-emitted by ``full_state_dict`` so a file saved here still loads in the
+    reference's strict ``load_state_dict`` (oc_classifier.py:340)."""
+
+    def __init__(self, device="cuda", cp_path=None, state_dict=None, cfg=None, dtype=torch.bfloat16, seed=0, finetune=False, synthetic=False,
+                 train_cfg=None):
         super().__init__()
         self.device = device
         self.cfg = cfg or XlsrConfig.xlsr_300m()
         self.out_dim = self.cfg.dim
+        self.ckpt_cfg = None
         if state_dict is None and cp_path is not None:
             ck = torch.load(cp_path, map_location="cpu")
             state_dict = ck.get("model", ck)
+            self.ckpt_cfg = ck.get("cfg") if isinstance(ck, dict) else None
         if state_dict is None:
+            if not synthetic:
+                raise OccError("SSLModel needs XLS-R weights: pass cp_path= / state_dict= (fairseq names), or synthetic=True for the "
+                               "deterministic random filler (tests and bench.py only)")
             state_dict = synthetic_params(self.cfg, seed)
-        self._params = {k: v for k, v in state_dict.items() if k in param_shapes(self.cfg)}
-        missing = set(param_shapes(self.cfg)) - set(self._params)
-        if missing:
-            raise OccError("XLS-R state_dict lacks %d tensors, e.g. %s" % (len(missing), sorted(missing)[:3]))
+        shapes = param_shapes(self.cfg)
+        self._params = {k: v for k, v in state_dict.items() if k in shapes}
+        self.extra_state = {k: v for k, v in state_dict.items() if k not in shapes}
+        check_param_shapes(self._params, shapes)
         self.finetune = finetune
+        self.train_cfg = train_cfg or XlsrTrainCfg.from_checkpoint_cfg(self.ckpt_cfg)
         if finetune == "encoder":      # transformer encoder trainable, conv feature extractor frozen (feature_grad_mult = 0 style)
             self.model = XlsrFineTuner(self._params, self.cfg, device=device)
         elif finetune:                 # the reference's optimizer holds every SSL parameter (oc_training.py:324): end-to-end
             self.model = XlsrFullFineTuner(self._params, self.cfg, device=device)
         else:
             self.model = XlsrFrontend(self._params, self.cfg, device=device, dtype=dtype)
+        if finetune:
+            self.model.train_cfg = self.train_cfg
 
     def extract_feat(self, input_data):
         with torch.no_grad():
@@ -244,6 +258,67 @@ class SSLModel(torch.nn.Module):
 
     def forward(self, input_data):
         return self.extract_feat(input_data)
+
+    def full_state_dict(self):
+        """Every tensor of the loaded checkpoint under its fairseq name: the path's tensors (the trained values when fine-tuning) plus
+        the untouched off-path ones."""
+        out = dict(self._params)
+        if self.finetune:
+            out.update(self.model.export_params())
+        out.update(self.extra_state)
+        return out
+
+    def load_params(self, sd, strict=True):
+        """sd: {fairseq name: tensor}.  strict: every tensor of the path must be present with its shape; others are kept as extra state."""
+        shapes = param_shapes(self.cfg)
+        new = {k: v for k, v in sd.items() if k in shapes}
+        if strict:
+            check_param_shapes(new, shapes)
+        else:
+            check_param_shapes(new, {k: shapes[k] for k in new})
+        self._params.update(new)
+        self.extra_state.update({k: v for k, v in sd.items() if k not in shapes})
+        if self.finetune:
+            self.model._load_master(self._params)
+            self.model.refresh_operands()
+        else:
+            self.model.pack(self._params)
+
+
+def check_param_shapes(params, shapes):
+    missing = sorted(set(shapes) - set(params))
+    if missing:
+        raise OccError("XLS-R state_dict lacks %d tensors, e.g. %s" % (len(missing), missing[:3]))
+    bad = [(k, tuple(params[k].shape), tuple(shapes[k])) for k in shapes if tuple(params[k].shape) != tuple(shapes[k])]
+    if bad:
+        raise OccError("XLS-R state_dict has %d tensors of the wrong shape, e.g. %s is %s, expected %s" % ((len(bad),) + bad[0]))
+
+
+class XlsrTrainCfg:
+    """Train-mode behaviour of fairseq's Wav2Vec2Model that the reference switches on with ``aasist.train()`` (oc_training.py:351;
+    sslassist.SSLModel never calls ``.eval()``, sslassist.py:20-29).  Values come from the checkpoint's ``cfg`` (fairseq: ``cfg.model``);
+    the defaults are those of the published XLS-R pre-training configuration (all zero, feature_grad_mult 1.0)."""
+    FIELDS = ("dropout", "attention_dropout", "activation_dropout", "encoder_layerdrop", "dropout_input", "dropout_features", "feature_grad_mult")
+
+    def __init__(self, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, dropout_input=0.0, dropout_features=0.0,
+                 feature_grad_mult=1.0):
+        self.dropout, self.attention_dropout, self.activation_dropout = float(dropout), float(attention_dropout), float(activation_dropout)
+        self.encoder_layerdrop, self.dropout_input, self.dropout_features = float(encoder_layerdrop), float(dropout_input), float(dropout_features)
+        self.feature_grad_mult = float(feature_grad_mult)
+
+    @classmethod
+    def from_checkpoint_cfg(cls, cfg):
+        if cfg is None:
+            return cls()
+        m = cfg.get("model", cfg) if isinstance(cfg, dict) else getattr(cfg, "model", cfg)
+        get = (lambda k: m.get(k)) if isinstance(m, dict) else (lambda k: getattr(m, k, None))
+        return cls(**{k: get(k) for k in cls.FIELDS if get(k) is not None})
+
+    def any_dropout(self):
+        return any(getattr(self, k) > 0 for k in self.FIELDS[:6])
+
+    def __repr__(self):
+        return "XlsrTrainCfg(%s)" % ", ".join("%s=%g" % (k, getattr(self, k)) for k in self.FIELDS)
 
 
 def synthetic_params(cfg, seed=0):

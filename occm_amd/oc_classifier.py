@@ -106,8 +106,13 @@ def main(argv=None):
     args = parser.parse_args(argv)
     from .models.sslassist import AModel
     device = torch.device("cuda")
-    aasist = AModel(None, device)
-    aasist.load_state_dict(torch.load(args.pretrained_sslaasist, map_location="cpu"))
+    # The reference builds AModel (which loads the fairseq file from a hard-coded path) and then overwrites every tensor with the trained
+    # checkpoint (oc_classifier.py:335-340, strict).  That checkpoint already holds all ``ssl_model.model.*`` tensors, so here it is the one
+    # source of the XLS-R weights; a tensor that is missing or has the wrong shape is an error, never a silently random front-end.
+    sd = torch.load(args.pretrained_sslaasist, map_location="cpu")
+    ssl = {k[len("ssl_model.model."):]: v for k, v in sd.items() if k.startswith("ssl_model.model.")}
+    aasist = AModel(None, device, ssl_state_dict=ssl)
+    aasist.load_state_dict(sd, strict=True)
     print("Pretrained weights loaded")
     train_loader = DataLoader(ASVDataset(args.protocol_file, args.dataset_dir), batch_size=1, shuffle=False, num_workers=0)
     reference_embedding, threshold = create_reference_embedding2(aasist, train_loader, device)

@@ -106,7 +106,12 @@ def main(argv=None):
     parser.add_argument("--w_descr", type=float, default=1.0)
     parser.add_argument("--vocoded_dir", type=str, default="/datab/Dataset/ASVspoof/LA/ASVspoof2019_LA_vocoded")
     parser.add_argument("--rawboost_algo", type=int, default=0)
-    parser.add_argument("--ssl_checkpoint", type=str, default=None, help="torch file with fairseq-named XLS-R weights")
+    parser.add_argument("--ssl_checkpoint", type=str, default="/datad/pretrained/fairseq/xlsr2_300m.pt",
+                        help="fairseq XLS-R checkpoint ({'model': ..., 'cfg': ...} or a bare state dict); default = the path the reference hard-codes "
+                        "(sslassist.py:24).  A missing file is an error, as in the reference")
+    parser.add_argument("--synthetic_ssl", action="store_true", help="tests only: deterministic random XLS-R weights instead of a checkpoint")
+    for _k in ("dropout", "attention_dropout", "activation_dropout", "encoder_layerdrop", "dropout_input"):
+        parser.add_argument("--ssl_" + _k, type=float, default=None, help="fairseq train-mode %s of XLS-R when --finetuned (default: the checkpoint's cfg)" % _k)
     parser.add_argument("--wandb", action="store_true")
     # not in the reference: the back-end class (its --model flag is parsed but never read: oc_training.py:320 always builds AModel),
     # loader workers (the reference uses num_workers=0; at thousands of utterances/s the decode has to run ahead of the GPU)
@@ -118,6 +123,9 @@ def main(argv=None):
     args = parser.parse_args(argv)
     if args.num_workers > 0 and args.rawboost_algo and not args.rawboost_on_gpu:
         raise ValueError("dataset-side RawBoost runs on the GPU of the main process: use --num_workers 0 or --rawboost_on_gpu")
+    ssl_kw = {"synthetic_ssl": True} if args.synthetic_ssl else {"ssl_cp_path": args.ssl_checkpoint}
+    if not args.synthetic_ssl and not os.path.exists(args.ssl_checkpoint):
+        raise FileNotFoundError("XLS-R checkpoint %s not found (--ssl_checkpoint); the reference loads it unconditionally (sslassist.py:24-26)" % args.ssl_checkpoint)
     print("*************************************************")
     for k in ("train_dataset_dir", "test_dataset_dir", "model", "finetuned", "train_protocol_file", "test_protocol_file"):
         print(f"{k} = {getattr(args, k)}")
@@ -134,21 +142,21 @@ def main(argv=None):
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, world, rank, shuffle=True) if world > 1 else None
     loader = DataLoader(dataset, batch_size=1, shuffle=sampler is None, sampler=sampler, num_workers=args.num_workers, pin_memory=True,
                         persistent_workers=args.num_workers > 0, prefetch_factor=4 if args.num_workers > 0 else None)
-    ssl_sd = None
-    if args.ssl_checkpoint:
-        ck = torch.load(args.ssl_checkpoint, map_location="cpu")
-        ssl_sd = ck.get("model", ck)
     # --finetuned: train XLS-R end to end as the reference's optimizer does (oc_training.py:324 holds every SSL parameter); without it
     # the front-end is frozen (BASELINE configs[1]) and its features for the next batch are computed under the current update
     ft = "full" if args.finetuned else False
     if args.backend == "senet":
         from .models.senet import ssl_resnet34
-        model = ssl_resnet34(device, ssl_state_dict=ssl_sd, finetune_ssl=ft)
+        model = ssl_resnet34(device, finetune_ssl=ft, **ssl_kw)
     else:
-        model = AModel(None, device, ssl_state_dict=ssl_sd, finetune_ssl=ft)
+        model = AModel(None, device, finetune_ssl=ft, **ssl_kw)
+    tc = model.ssl_model.train_cfg
+    for _k in ("dropout", "attention_dropout", "activation_dropout", "encoder_layerdrop", "dropout_input"):
+        if getattr(args, "ssl_" + _k) is not None:
+            setattr(tc, _k, getattr(args, "ssl_" + _k))
     model.train()
     trainer = OcTrainer(model, lr=args.lr, w_compact=args.w_compact, w_descr=args.w_descr, train_frontend=bool(ft),
-                        rawboost_algo=args.rawboost_algo if args.rawboost_on_gpu else 0)
+                        rawboost_algo=args.rawboost_algo if args.rawboost_on_gpu else 0, rank=rank)
     wb = None
     if args.wandb and rank == 0:
         import wandb as wb

@@ -23,7 +23,7 @@ def init_from_env(backend=None):
         if backend is None:     # OCC_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
             backend = os.environ.get("OCC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

@@ -13,9 +13,10 @@ class OcTrainer:
     0.0 / 1.0 (oc_training.py:380-381); the SE-ResNet script uses 0.1 / 0.9 (test_dataloader_v2.py:127)."""
 
     def __init__(self, model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=False, group_size=None, dropout_masks=None, rawboost_algo=0,
-                 rawboost_args=None, seed=0):
+                 rawboost_args=None, seed=0, rank=0):
         self.model = model
-        self.rawboost_algo, self.rawboost_args, self.seed, self.nstep = rawboost_algo, rawboost_args, seed, 0
+        # every data-parallel rank draws its own augmentation parameters: the rank is part of the RawBoost seed
+        self.rawboost_algo, self.rawboost_args, self.seed, self.nstep = rawboost_algo, rawboost_args, seed * 4096 + rank, 0
         self.dropout_masks = dropout_masks      # None: draw masks on the device (normal training); {}: no dropout; dict: injected keep-masks
         self.be = model.backend
         self.fe = model.ssl_model.model

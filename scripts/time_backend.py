@@ -9,7 +9,7 @@ from occm_amd.models.sslassist import AModel
 from occm_amd.trainer import OcTrainer
 
 cfg = xlsr.XlsrConfig(dim=1024, ffn=64, heads=16, layers=1)          # tiny front-end: only the feature shape matters here
-model = AModel(None, "cuda", ssl_cfg=cfg, ssl_dtype=torch.bfloat16, seed=0)
+model = AModel(None, "cuda", ssl_cfg=cfg, ssl_dtype=torch.bfloat16, seed=0, synthetic_ssl=True)
 model.train()
 tr = OcTrainer(model, lr=1e-5, w_compact=0.0, w_descr=1.0)
 be = tr.be

@@ -344,7 +344,7 @@ def test_trainer_prefetch_pipeline_equals_sequential_steps():
     labels = (torch.arange(12) >= 6).long().cuda()
 
     def run(pipelined):
-        model = AModel(None, "cuda", ssl_cfg=cfg, seed=0)
+        model = AModel(None, "cuda", ssl_cfg=cfg, seed=0, synthetic_ssl=True)
         model.train()
         tr = OcTrainer(model, lr=1e-4, w_compact=0.1, w_descr=0.9, dropout_masks={})
         seen, fwd = [], tr.be.forward

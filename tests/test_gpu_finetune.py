@@ -144,7 +144,7 @@ def test_finetune_trainer_runs_and_learns():
     from occm_amd.models.sslassist import AModel
     from occm_amd.trainer import OcTrainer
     cfg = xlsr.XlsrConfig(dim=1024, ffn=512, heads=16, layers=2)      # AASIST's LL expects 1024-d features
-    model = AModel(None, "cuda", ssl_cfg=cfg, finetune_ssl="full", backend_compute="f32")
+    model = AModel(None, "cuda", ssl_cfg=cfg, finetune_ssl="full", backend_compute="f32", synthetic_ssl=True)
     before = {k: v.clone() for k, v in model.ssl_model.model.export_params().items()}
     tr = OcTrainer(model, lr=2e-4, w_compact=0.1, w_descr=0.9, train_frontend=True, dropout_masks={})   # no dropout: deterministic descent
     wav = (0.1 * _r(12, 16000, seed=1)).cuda()

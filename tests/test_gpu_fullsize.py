@@ -65,7 +65,7 @@ def test_training_step_bs32_conservation():
     from occm_amd.models.sslassist import AModel
     from occm_amd.trainer import OcTrainer
     cfg = xlsr.XlsrConfig(dim=1024, ffn=1024, heads=16, layers=2)       # full-size back-end and batch, short encoder (front-end covered above)
-    model = AModel(None, "cuda", ssl_cfg=cfg, seed=0)
+    model = AModel(None, "cuda", ssl_cfg=cfg, seed=0, synthetic_ssl=True)
     model.train()
     lr = 1e-3
     tr = OcTrainer(model, lr=lr, w_compact=0.0, w_descr=1.0)

@@ -1,0 +1,109 @@
+"""The 256x256 eight-phase bf16 GEMM (csrc/gemm_p8.hip) through occ_gemm: exact-integer checks of the whole tile/fragment/DMA
+addressing (small-integer bf16 operands make every f32 sum exact, so any misplaced row, chunk or k-step shows as an integer
+difference), ragged tile edges, odd / one / two K-tiles, conv windows through row maps, epilogues, and a run-to-run race screen."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _force_p8():
+    from occm_amd._lib import lib
+    prev = lib().occ_gemm_variant(30)
+    yield
+    lib().occ_gemm_variant(prev)
+
+
+def _ints(rows, cols, seed, lo=-3, hi=3):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, (rows, cols), generator=g).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 256, 192), (300, 256, 320), (1000, 512, 1024), (257, 768, 1536),
+                                   (12736, 1024, 1024), (6368, 4096, 1024), (2049, 260, 448)])
+def test_p8_exact_integer_products(M, N, K):
+    from occm_amd import ops
+    x, w = _ints(M, K, 1), _ints(N, K, 2)                 # asymmetric operands: a swapped row/column map cannot cancel
+    bias = _ints(1, N, 3)[0]
+    ref = x.double() @ w.double().T + bias.double()
+    out = torch.full((M, N), 7777.0, device="cuda")
+    ops.gemm_raw(M, N, K, x.bfloat16().cuda(), ops.rowmap(M, 0, K), w.bfloat16().cuda(), K, out, ops.rowmap(M, 0, N), ops.OCC_F32, ops.OCC_BF16, bias=bias.cuda())
+    assert torch.equal(out.cpu().double(), ref), (M, N, K, float((out.cpu().double() - ref).abs().max()))
+
+
+def test_p8_conv_windows_and_padded_output_rows():
+    """Conv1d(k=3, s=2) as overlapping row windows (row stride s*C < K) into an output whose rows sit inside a padded buffer."""
+    from occm_amd import ops
+    B, Tin, C, k, s = 3, 701, 512, 3, 2
+    Tout = (Tin - k) // s + 1
+    x = _ints(B * Tin, C, 5, -2, 2)
+    w = _ints(512, k * C, 6, -2, 2)
+    xb = x.bfloat16().cuda()
+    out = torch.zeros(B, Tout + 2, 512, device="cuda")
+    ops.gemm_raw(B * Tout, 512, k * C, xb, ops.rowmap(Tout, Tin * C, s * C), w.bfloat16().cuda(), k * C,
+                 out.data_ptr() + 512 * 4, ops.rowmap(Tout, (Tout + 2) * 512, 512), ops.OCC_F32, ops.OCC_BF16)
+    win = x.view(B, Tin, C).unfold(1, k, s).permute(0, 1, 3, 2).reshape(B * Tout, k * C)      # [b, t, tap, c]
+    ref = (win.double() @ w.double().T).view(B, Tout, 512)
+    assert torch.equal(out[:, 1:-1].cpu().double(), ref)
+    assert float(out[:, 0].abs().max()) == 0 and float(out[:, -1].abs().max()) == 0           # the pad rows were not touched
+
+
+@pytest.mark.parametrize("gelu,res,cbf", [(True, False, True), (False, True, False), (True, True, True), (False, False, True)])
+def test_p8_epilogues_random_data(gelu, res, cbf):
+    from occm_amd import ops
+    M, N, K = 1531, 1024, 512
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(M, K, generator=g) * 0.5).bfloat16(); w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(N, generator=g); r = torch.randn(M, N, generator=g)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16 if cbf else torch.float32)
+    ops.gemm_raw(M, N, K, x.cuda(), ops.rowmap(M, 0, K), w.cuda(), K, out, ops.rowmap(M, 0, N), ops.OCC_BF16 if cbf else ops.OCC_F32, ops.OCC_BF16,
+                 bias=b.cuda(), act=ops.ACT_GELU if gelu else ops.ACT_NONE, R=r.cuda() if res else None, r_map=ops.rowmap(M, 0, N), r_dtype=ops.OCC_F32)
+    ref = x.float() @ w.float().T + b
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + r
+    torch.testing.assert_close(out.cpu().float(), ref, rtol=1e-2 if cbf else 1e-4, atol=2e-2 if cbf else 1e-4)
+
+
+def test_p8_gelu_aux_and_gelu_grad():
+    from occm_amd import ops
+    M, N, K = 777, 512, 256
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(M, K, generator=g) * 0.5).bfloat16(); w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(N, generator=g)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); aux = torch.empty_like(out)
+    ops.gemm_raw(M, N, K, x.cuda(), ops.rowmap(M, 0, K), w.cuda(), K, out, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16, bias=b.cuda(), act=ops.ACT_GELU, aux=aux)
+    pre = x.float() @ w.float().T + b
+    torch.testing.assert_close(aux.cpu().float(), pre, rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(out.cpu().float(), torch.nn.functional.gelu(pre), rtol=1e-2, atol=2e-2)
+    dy = (torch.randn(M, K, generator=g)).bfloat16()
+    du = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_raw(M, N, K, dy.cuda(), ops.rowmap(M, 0, K), w.cuda(), K, du, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16, act=ops.ACT_GELU_GRAD, aux=aux)
+    u = aux.cpu().float().requires_grad_(True)
+    torch.nn.functional.gelu(u).backward(dy.float() @ w.float().T)
+    torch.testing.assert_close(du.cpu().float(), u.grad, rtol=2e-2, atol=3e-2)
+
+
+def test_p8_race_screen_bitwise_repeatable():
+    """A fragment read ahead of its DMA (or a DMA over a buffer still being read) would show as run-to-run differences: 30 launches per
+    shape, interleaved with launches of other shapes that change the memory timing, must be bit-identical."""
+    from occm_amd import ops
+    g = torch.Generator().manual_seed(13)
+    shapes = [(6368, 1024, 4096), (12736, 3072, 1024), (4096, 4096, 4096), (1111, 512, 1536)]
+    ops_ = []
+    for M, N, K in shapes:
+        x = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda(); w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+        ops_.append((M, N, K, x, w, torch.empty(M, N, device="cuda")))
+    first = {}
+    for it in range(30):
+        for i, (M, N, K, x, w, out) in enumerate(ops_):
+            out.fill_(float("nan"))
+            ops.gemm_raw(M, N, K, x, ops.rowmap(M, 0, K), w, K, out, ops.rowmap(M, 0, N), ops.OCC_F32, ops.OCC_BF16)
+            if it == 0:
+                first[i] = out.clone()
+                ref = x.float() @ w.float().T
+                torch.testing.assert_close(out, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+            else:
+                assert torch.equal(out, first[i]), (it, M, N, K)

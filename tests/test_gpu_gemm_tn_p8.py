@@ -1,0 +1,75 @@
+"""The 256x256 eight-phase weight-gradient kernel (csrc/gemm_tn_p8.hip) through occ_gemm_tn: exact-integer checks (small-integer bf16
+operands: every f32 partial sum is exact, so the slab / ticket reduction is order-independent and any misplaced row, column block
+or k-slot is an integer difference), reduction pieces with and without a workspace, a row count that is not a multiple of 64 (the
+tail goes through the small-tile kernel), conv windows through row maps, accumulation onto a non-zero C, a run-to-run race screen."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ints(rows, cols, seed, lo=-2, hi=2):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, (rows, cols), generator=g).float()
+
+
+@pytest.mark.parametrize("M,N1,N2", [(1024, 256, 256), (12736, 1024, 1024), (12736, 4096, 1024), (6368, 1024, 3072), (2000, 512, 256), (1088, 256, 768)])
+@pytest.mark.parametrize("use_ws", [True, False])
+def test_tn_p8_exact_integer_products(M, N1, N2, use_ws):
+    from occm_amd import backend_ops as K
+    a, b = _ints(M, N1, 1), _ints(M, N2, 2)
+    c0 = _ints(N1, N2, 3, -50, 50)
+    C = c0.clone().cuda()
+    s = torch.zeros(N1, device="cuda")
+    if not use_ws:
+        K._TN_WS.clear()
+        saved, K.TN_WORKSPACE_BYTES = K.TN_WORKSPACE_BYTES, 16            # too small for any slab: one piece per tile
+    try:
+        K.gemm_tn(M, N1, N2, a.bfloat16().cuda(), K.full(M, N1), b.bfloat16().cuda(), K.full(M, N2), C, N2, alpha=0.5, colsum_out=s, a_bf16=True, b_bf16=True,
+                  bf16_mfma=True)
+    finally:
+        if not use_ws:
+            K.TN_WORKSPACE_BYTES = saved
+            K._TN_WS.clear()
+    ref = c0.double() + 0.5 * (a.double().T @ b.double())
+    assert torch.equal(C.cpu().double(), ref), float((C.cpu().double() - ref).abs().max())
+    assert torch.equal(s.cpu().double(), 0.5 * a.double().sum(0))
+
+
+def test_tn_p8_conv_windows_row_maps():
+    """Conv1d(k=3, s=2) weight gradient: X rows are overlapping windows of the channels-last activation (row stride s*C, one batch
+    stride per utterance), dY rows sit inside a buffer with one pad row in front of every utterance."""
+    from occm_amd import backend_ops as K
+    B, Tin, Cc, k, st = 4, 1025, 512, 3, 2
+    Tout = (Tin - k) // st + 1                      # 512 -> M = 2048
+    M = B * Tout
+    x = _ints(B * Tin, Cc, 5)
+    dy_pad = torch.zeros(B, Tout + 2, 512)
+    dy_pad[:, 1:-1] = _ints(M, 512, 6).view(B, Tout, 512)
+    C = torch.zeros(512, k * Cc, device="cuda")
+    dyd = dy_pad.bfloat16().cuda()
+    K.gemm_tn(M, 512, k * Cc, dyd.data_ptr() + 512 * 2, K.rowmap(Tout, (Tout + 2) * 512, 512), x.bfloat16().cuda(), K.rowmap(Tout, Tin * Cc, st * Cc), C, k * Cc,
+              a_bf16=True, b_bf16=True, bf16_mfma=True)
+    win = x.view(B, Tin, Cc).unfold(1, k, st).permute(0, 1, 3, 2).reshape(M, k * Cc)
+    ref = dy_pad[:, 1:-1].reshape(M, 512).double().T @ win.double()
+    assert torch.equal(C.cpu().double(), ref)
+
+
+def test_tn_p8_random_data_and_race_screen():
+    from occm_amd import backend_ops as K
+    g = torch.Generator().manual_seed(7)
+    probs = []
+    for M, N1, N2 in [(12736, 1024, 4096), (12736, 3072, 1024), (6368, 1024, 1024)]:
+        a = torch.randn(M, N1, generator=g).bfloat16().cuda(); b = torch.randn(M, N2, generator=g).bfloat16().cuda()
+        probs.append((M, N1, N2, a, b, torch.empty(N1, N2, device="cuda")))
+    first = {}
+    for it in range(12):
+        for i, (M, N1, N2, a, b, C) in enumerate(probs):
+            C.zero_()
+            K.gemm_tn(M, N1, N2, a, K.full(M, N1), b, K.full(M, N2), C, N2, a_bf16=True, b_bf16=True, bf16_mfma=True)
+            if it == 0:
+                ref = a.float().T @ b.float()
+                torch.testing.assert_close(C, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+                first[i] = C.clone()
+            else:
+                assert torch.equal(C, first[i]), (it, M, N1, N2)         # fixed summation order: bit-reproducible

@@ -102,12 +102,46 @@ def test_oc_training_entry_point_runs_and_saves_checkpoint(tmp_path, monkeypatch
     for i in range(3):
         lines.append(f"LA_01{i} S{i} - A0{i} spoof"); _write_wav(str(d / f"S{i}.wav"), 15000 + 11 * i, 50 + i)
     (tmp_path / "prot.txt").write_text("\n".join(lines) + "\n")
+    # a fairseq-shaped checkpoint file: {"model": path tensors + the off-path tensors a real xlsr2_300m.pt also holds, "cfg": {...}}
+    small = xlsr.XlsrConfig.xlsr_300m()
+    ck_model = dict(xlsr.synthetic_params(small, 0))
+    g = torch.Generator().manual_seed(9)
+    extras = {"mask_emb": torch.rand(1024, generator=g), "quantizer.vars": torch.rand(1, 640, 384, generator=g),
+              "quantizer.weight_proj.weight": torch.rand(640, 512, generator=g), "quantizer.weight_proj.bias": torch.rand(640, generator=g),
+              "project_q.weight": torch.rand(768, 768, generator=g), "project_q.bias": torch.rand(768, generator=g),
+              "final_proj.weight": torch.rand(768, 1024, generator=g), "final_proj.bias": torch.rand(768, generator=g)}
+    ck_model.update(extras)
+    torch.save({"model": ck_model, "cfg": {"model": {"dropout": 0.0, "attention_dropout": 0.0, "activation_dropout": 0.0, "encoder_layerdrop": 0.0,
+                                                      "dropout_input": 0.0, "feature_grad_mult": 1.0}}, "args": None}, str(tmp_path / "xlsr.pt"))
     random.seed(0); torch.manual_seed(0)
     oc_training.main(["--train_protocol_file", str(tmp_path / "prot.txt"), "--train_dataset_dir", str(d), "--vocoded_dir", str(v), "--epochs", "1",
-                      "--lr", "1e-4"] + extra)
+                      "--lr", "1e-4", "--ssl_checkpoint", str(tmp_path / "xlsr.pt")] + extra)
     sd = torch.load(str(tmp_path / "aasist_vocoded_0.pt"), map_location="cpu")
     assert all(torch.isfinite(t.float()).all() for t in sd.values() if torch.is_tensor(t))
+    pre = "frontend.model." if "--backend" in extra else "ssl_model.model."
+    # the file holds EVERY tensor of the fairseq checkpoint under the reference's prefix (what its strict load_state_dict needs,
+    # oc_classifier.py:340), the off-path ones bit-identical, the path's ones with their shapes
+    assert {k[len(pre):] for k in sd if k.startswith(pre)} == set(ck_model)
+    for k, t in extras.items():
+        assert torch.equal(sd[pre + k], t)
+    for k, t in ck_model.items():
+        assert tuple(sd[pre + k].shape) == tuple(t.shape), k
+    trained = sum(int(not torch.equal(sd[pre + k].float(), ck_model[k])) for k in ck_model if k not in extras)
+    assert (trained > 50) if "--finetuned" in extra else (trained == 0)
     if "--backend" in extra:
-        assert "layer1.0.conv1.weight" in sd or any(k.endswith("layer1.0.conv1.weight") for k in sd)
+        assert any(k.endswith("layer1.0.conv1.weight") for k in sd)
     else:
-        assert "LL.weight" in sd and "out_layer.weight" in sd and any(k.startswith("ssl_model.model.") for k in sd)
+        assert "LL.weight" in sd and "out_layer.weight" in sd
+        # and it loads back, strictly, into a fresh model (the scorer's path); a file lacking one path tensor is rejected
+        from occm_amd.models.sslassist import AModel
+        from occm_amd._lib import OccError
+        ssl = {k[len(pre):]: t for k, t in sd.items() if k.startswith(pre)}
+        m2 = AModel(None, "cuda", ssl_state_dict=ssl)
+        m2.load_state_dict(sd, strict=True)
+        assert set(m2.state_dict()) == set(sd)
+        broken = {k: t for k, t in sd.items() if k != pre + "encoder.layers.0.fc1.weight"}
+        with pytest.raises(OccError):
+            m2.load_state_dict(broken, strict=True)
+        wrong = dict(sd); wrong[pre + "encoder.layers.0.fc1.bias"] = torch.zeros(7)
+        with pytest.raises(OccError):
+            m2.load_state_dict(wrong, strict=True)

@@ -197,7 +197,7 @@ def test_ssl_resnet34_trainer_learns(finetune):
     from occm_amd.models.senet import ssl_resnet34
     from occm_amd.trainer import OcTrainer
     cfg = xlsr.XlsrConfig(dim=256, ffn=512, heads=4, layers=2)
-    model = ssl_resnet34("cuda", ssl_cfg=cfg, finetune_ssl=finetune)
+    model = ssl_resnet34("cuda", ssl_cfg=cfg, finetune_ssl=finetune, synthetic_ssl=True)
     model.train()
     tr = OcTrainer(model, lr=1e-3 if not finetune else 2e-4, w_compact=0.1, w_descr=0.9, train_frontend=bool(finetune))
     wav = (0.1 * _x((12, 16000), 1)).cuda()

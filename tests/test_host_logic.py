@@ -122,3 +122,55 @@ def test_ops_fail_loudly_without_gpu():
         _lib.require_gpu()
     with pytest.raises(_lib.OccError):
         ops.linear(torch.zeros(4, 8), torch.zeros(4, 8))
+
+
+def test_missing_xlsr_checkpoint_is_an_error_not_a_random_frontend(tmp_path):
+    """The reference loads its fairseq file unconditionally (sslassist.py:24-26) and dies without it; so do the mirrors.  Random
+    stand-in weights exist only behind an explicit synthetic=True / --synthetic_ssl."""
+    from occm_amd import oc_training
+    from occm_amd._lib import OccError
+    from occm_amd.models.xlsr import SSLModel
+    with pytest.raises(FileNotFoundError):
+        oc_training.main(["--train_protocol_file", str(tmp_path / "p.txt"), "--ssl_checkpoint", str(tmp_path / "absent.pt")])
+    with pytest.raises(OccError, match="needs XLS-R weights"):
+        SSLModel("cuda")
+    with pytest.raises(OccError, match="lacks"):
+        SSLModel("cuda", state_dict={"layer_norm.weight": torch.ones(512)})
+
+
+def test_xlsr_train_cfg_reads_the_checkpoint_cfg():
+    from occm_amd.models.xlsr import XlsrTrainCfg
+    assert not XlsrTrainCfg.from_checkpoint_cfg(None).any_dropout()
+    c = XlsrTrainCfg.from_checkpoint_cfg({"model": {"dropout": 0.1, "encoder_layerdrop": 0.05, "feature_grad_mult": 0.1, "unrelated": 3}})
+    assert (c.dropout, c.encoder_layerdrop, c.attention_dropout, c.feature_grad_mult) == (0.1, 0.05, 0.0, 0.1) and c.any_dropout()
+
+    class NS:      # fairseq stores an omegaconf / argparse namespace rather than a dict
+        pass
+    ns, m = NS(), NS()
+    m.activation_dropout = 0.2
+    ns.model = m
+    assert XlsrTrainCfg.from_checkpoint_cfg(ns).activation_dropout == 0.2
+
+
+def test_bench_gpus_flag_starts_that_many_ranks(tmp_path):
+    """`python bench.py --gpus 2 --dry-launch`: the parent starts two ranks (torch.distributed.run) before touching a GPU; both reach
+    init_process_group (gloo), agree on world == 2 and shard 4 groups of 12 as [0,2) / [2,4); rank 0 prints one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["ok"] and out["n_groups"] == 4
+    assert sorted((s["rank"], tuple(s["groups"])) for s in out["ranks"]) == [(0, (0, 2)), (1, (2, 4))]
+    # one rank, no launcher
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-launch"], capture_output=True, text=True, env=env, timeout=300)
+    assert r1.returncode == 0 and json.loads(r1.stdout.splitlines()[-1])["n_gpus"] == 1
+    # a rank count that disagrees with the environment is refused
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True, env=env2, timeout=300)
+    assert r2.returncode != 0 and "process group has 1 ranks" in (r2.stderr + r2.stdout)
