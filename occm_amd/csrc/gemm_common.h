@@ -30,6 +30,9 @@ struct GemmArgs {
     int slabs_per_split;
     int tile_rows;           // default 128x128 kernels: rows per output tile (multiple of 16, <= 128; the LDS image stays 128 rows) -- see occ_gemm
     int dbg;                 // ablation bits (timing experiments only, results wrong): 1 no loads in the K loop, 2 no MFMA, 4 no fragment reads
+#ifdef P8_DIAG
+    unsigned long long* diag;   // scripts/diag_p8.hip only: per workgroup {clock at entry, after the prologue, after the K loop, at exit, realtime entry, realtime exit}
+#endif
 };
 
 __device__ __forceinline__ float act_rt(int act, float v) {

@@ -61,6 +61,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
         tile_n = loc / gsz;
     }
     const long long m0 = (long long)tile_m * 256, n0 = (long long)tile_n * 256;
+#ifdef P8_DIAG
+    const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -126,6 +129,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
     __builtin_amdgcn_sched_barrier(0);
     if (wr == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }       // the lagging wave row
 
+#ifdef P8_DIAG
+    const unsigned long long dg_t1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     u32x4 w0[2][2], w1[2][2], x[4][2];         // [16-row block][k-step]
     auto tile = [&](auto bufc, const int t) {
         constexpr int B = decltype(bufc)::value;
@@ -179,7 +186,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
     if (t < nt) tile(std::integral_constant<int, 0>{}, t);
     if (wr == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }        // pairs with the lagging row's last barrier
 
+#ifdef P8_DIAG
+    const unsigned long long dg_t2 = __builtin_amdgcn_s_memtime();
+#endif
     gemm_epilogue<8>(a, acc, m0 + wr * 128, n0 + wc * 64, fr, fq, 0);
+#ifdef P8_DIAG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+        unsigned long long* o = a.diag + (long long)blockIdx.x * 6;
+        o[0] = dg_t0; o[1] = dg_t1; o[2] = dg_t2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = dg_r0; o[5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // Launch helper used by occ_gemm.  Preconditions (checked by the caller): bf16 operands, K % 64 == 0, one K segment, one group.
