@@ -302,10 +302,12 @@ int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, 
 int occ_transpose_bf16_rows(const void* src, int src_dtype, const occ_rowmap* src_map, void* dst, int64_t rows, int64_t cols,
                             int64_t ld_dst, float* colsum, void* stream);
 /* General form: x f32 or bf16; gelu != 0 treats dy as the gradient wrt gelu(LN(x)) (conv blocks of the feature extractor, needs
- * beta); dx (f32, contiguous) and dx_bf16 (through dx_bf16_map, NULL = contiguous) are each optional.                      */
+ * beta); dx (f32, contiguous) and dx_bf16 (through dx_bf16_map, NULL = contiguous) are each optional.
+ * scratch (optional, caller-owned, 16-byte aligned, 512*C floats cover every case): the per-workgroup dgamma / dbeta sums go
+ * through it (plain stores + a small second launch) instead of global float atomics; NULL = atomics.                       */
 int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
                          const float* dres, float* dx, void* dx_bf16, const occ_rowmap* dx_bf16_map, float* dgamma, float* dbeta,
-                         int64_t rows, int64_t C, float eps, int gelu, void* stream);
+                         int64_t rows, int64_t C, float eps, int gelu, float* scratch, int64_t scratch_floats, void* stream);
 /* out (bf16, through out_map) = dy (f32 [rows,C]) * gelu'(u (bf16 [rows,C])): gradient through the positional conv's GELU.   */
 int occ_gelu_bwd_rows(const float* dy, const void* u, void* out, const occ_rowmap* out_map, int64_t rows, int64_t C, void* stream);
 /* Backward of occ_conv0_ln_gelu (recomputes the block from the waveform): dw [C,k], dbias, dgamma, dbeta accumulated.       */
@@ -320,11 +322,12 @@ int occ_weight_norm_bwd(const float* v, const float* g, const float* norms, cons
                         int64_t I, int64_t K, int64_t G, void* stream);
 /* dx_bf16 (optional): a bf16 copy of dx for the next input-gradient GEMMs.                                             */
 int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16,
-                      float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, void* stream);
+                      float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, float* scratch, int64_t scratch_floats, void* stream);
 /* dq|dk|dv (bf16 [B*T, 3D], same layout as qkv) of softmax(scale q.k^T) v given o (forward output), dout and the forward's lse.
- * head_dim 64, T <= 256.                                                                                     */
+ * head_dim 64 or 80, any T.  T > 256 needs dq_accum: caller-owned f32 scratch [B*T, H*hd] (16-byte aligned) in which the key blocks
+ * of a head meet; it may be NULL for T <= 256.                                                                   */
 int occ_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H,
-                      int64_t hd, int64_t ld_qkv, int64_t ld_o, float scale, void* stream);
+                      int64_t hd, int64_t ld_qkv, int64_t ld_o, float scale, float* dq_accum, void* stream);
 
 /* ---- LFCC front-end (replaces utils.py:127-138 extract_lfcc -> spafe lfcc; parity unpinned: oracle/lfcc_ref.py) ----
  * The DFT, the linear filter bank and the DCT run as f32 occ_gemm calls; these are the stages between them.

@@ -1,0 +1,335 @@
+// Backward of fairseq MultiheadAttention's softmax(scale q.k^T) v inside XLS-R (reached from sslassist.py:48 when the front-end is
+// fine-tuned, oc_training.py:324) for any sequence length and head dims 64 (XLS-R-300M) and 80 (XLS-R-1B).
+//
+// One workgroup = 8 waves (2 per SIMD) = one (batch, head) x one block of 256 keys.  Keys live on the MFMA lane: every wave owns up to
+// two 16-key tiles (tile w and w + 8 of the block) and keeps their K / V row fragments and their dK^T / dV^T accumulators in
+// registers while the workgroup sweeps the queries in steps of 32:
+//     S = Q.K^T and dP = dO.V^T           (A = Q / dO rows from the LDS slice, B = K / V fragments)     -> lane: 4 queries x 1 key
+//     P = exp2(S*c - lse[q]),  dS = P * (dP - delta[q])         (lse from the forward, delta = rowsum(dO * O) computed per slice)
+//     dV^T += dO^T.P,  dK^T += Q^T.dS     (A = transposing reads of the dO / Q slice, B = the packed P / dS registers)
+//     dS -> LDS [32][keys];  dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]    (A = transposing reads of the K image, B = dS rows)
+// k-slot (g, u, j) of a 32-deep contraction <-> row 16u + 4g + j on both operands of the three transposed products.
+// The Q / dO slices are row-major [32][HD] (next slice prefetched into registers under the current step); 128-byte rows (HD = 64)
+// are XOR-swizzled so that both the row reads (ds_read_b128) and the transposing reads are bank-conflict free.
+// dQ: with one key block (T <= 256) it is complete inside the workgroup and stored as bf16; with more key blocks every workgroup adds
+// its part to the caller's f32 accumulator (atomics, different key blocks of one head) and attention_dq_finish_kernel rounds it.
+#include "occ_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ u32x2 ab_tr_read(unsigned addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+template <int HD> struct AbCfg {
+    static constexpr int KS = (HD + 31) / 32;          // 32-deep contraction steps over the head dim (80 -> 3, zero padded)
+    static constexpr int DT = HD / 16;                 // 16-wide d tiles
+    static constexpr int CH = HD / 8;                  // 16-byte chunks per row
+    static constexpr int ROWB = HD == 64 ? 128 : 208;  // LDS row bytes of the Q / dO slices and the K image (96 elements + pad for HD = 80)
+    static constexpr bool SWZ = HD == 64;
+};
+constexpr int AB_KEYS = 256, AB_DS_STRIDE = AB_KEYS + 8;      // dS rows: 16-byte aligned, 8-element pad
+
+// byte offset of 16-byte chunk c of row r in a slice / image
+template <int HD> __device__ __forceinline__ unsigned ab_off(int r, int c) {
+    if (AbCfg<HD>::SWZ) return (unsigned)(r * 128 + ((c ^ (((r >> 1) & 3) << 1)) << 4));
+    return (unsigned)(r * AbCfg<HD>::ROWB + c * 16);
+}
+
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ o,
+                                                               const unsigned short* __restrict__ dout, const float* __restrict__ lse,
+                                                               unsigned short* __restrict__ dqkv, float* __restrict__ dq_accum, int Tn, int H,
+                                                               long long ld_qkv, long long ld_o, float scale) {
+    using C = AbCfg<HD>;
+    constexpr int KS = C::KS, DT = C::DT, CH = C::CH, ROWB = C::ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned char* Kimg = sm;                                        // [256][ROWB]
+    unsigned char* Qs = Kimg + AB_KEYS * ROWB;                       // [2][32][ROWB]
+    unsigned char* dOs = Qs + 2 * 32 * ROWB;                         // [2][32][ROWB]
+    unsigned short* dSs = reinterpret_cast<unsigned short*>(dOs + 2 * 32 * ROWB);       // [32][AB_DS_STRIDE]
+    float* lse_s = reinterpret_cast<float*>(dSs + 32 * AB_DS_STRIDE);                   // [2][32]
+    float* dlt_s = lse_s + 64;                                                          // [2][32]
+    const int D = H * HD;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H, kb = blockIdx.y;
+    const int key0 = kb * AB_KEYS;
+    const int nkeys = Tn - key0 < AB_KEYS ? Tn - key0 : AB_KEYS;     // keys of this block (>= 1)
+    const int nkt = (nkeys + 15) >> 4;                               // 16-key tiles in use
+    const unsigned short* qbase = qkv + (size_t)b * Tn * ld_qkv + (size_t)h * HD;
+    const unsigned short* kbase = qbase + D;
+    const unsigned short* vbase = qbase + 2 * D;
+    const unsigned short* obase = o + (size_t)b * Tn * ld_o + (size_t)h * HD;
+    const unsigned short* dobase = dout + (size_t)b * Tn * ld_o + (size_t)h * HD;
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)sm;
+
+    // ---- K image of this key block (rows beyond the last key and the pad columns of HD = 80 are zero)
+    for (int idx = tid; idx < AB_KEYS * (ROWB / 16); idx += 512) {
+        const int r = idx / (ROWB / 16), c = idx - r * (ROWB / 16);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < nkeys && c < CH) v = *reinterpret_cast<const uint4*>(kbase + (size_t)(key0 + r) * ld_qkv + c * 8);
+        if (C::SWZ) { if (c < CH) *reinterpret_cast<uint4*>(Kimg + ab_off<HD>(r, c)) = v; }
+        else *reinterpret_cast<uint4*>(Kimg + r * ROWB + c * 16) = v;
+    }
+    // ---- this wave's key tiles: K and V row fragments in registers (B operands of S and dP: column = key fr, k = 8 consecutive d)
+    u32x4 kf[2][KS], vf[2][KS];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int key = (wave + 8 * kk) * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kf[kk][s] = (u32x4){0, 0, 0, 0}; vf[kk][s] = kf[kk][s];
+            const int d0 = s * 32 + g * 8;
+            if (key < nkeys && d0 < HD) {
+                const uint4 kv = *reinterpret_cast<const uint4*>(kbase + (size_t)(key0 + key) * ld_qkv + d0);
+                const uint4 vv = *reinterpret_cast<const uint4*>(vbase + (size_t)(key0 + key) * ld_qkv + d0);
+                kf[kk][s] = (u32x4){kv.x, kv.y, kv.z, kv.w}; vf[kk][s] = (u32x4){vv.x, vv.y, vv.z, vv.w};
+            }
+        }
+    }
+    f32x4 dvacc[DT][2], dkacc[DT][2];                  // [d tile][key tile]: rows d = 16*dt + 4g + r, column key = 16*tile + fr
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { dvacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkacc[i][j] = dvacc[i][j]; }
+    const float c2 = scale * 1.44269504088896340736f;
+
+    // ---- slice staging: thread -> (row, chunk) items of the 32 x CH chunk grid; the lower half of the workgroup carries Q (+ lse),
+    // the upper half dO and O (+ delta = rowsum(dO * O), added up per row with LDS float atomics: CH adds per row and step)
+    const int half = tid >> 8, ht = tid & 255;
+    constexpr int NIT = (32 * CH + 255) / 256;
+    uint4 pa[NIT], pb[NIT];                            // prefetched chunks: Q (lower half) or dO / O (upper half)
+    float plse = 0.f;
+    auto prefetch = [&](int q0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = ht + it * 256, r = idx / CH, c = idx - r * CH;
+            pa[it] = make_uint4(0, 0, 0, 0); pb[it] = pa[it];
+            if (idx < 32 * CH && q0 + r < Tn) {
+                if (half == 0) pa[it] = *reinterpret_cast<const uint4*>(qbase + (size_t)(q0 + r) * ld_qkv + c * 8);
+                else { pa[it] = *reinterpret_cast<const uint4*>(dobase + (size_t)(q0 + r) * ld_o + c * 8); pb[it] = *reinterpret_cast<const uint4*>(obase + (size_t)(q0 + r) * ld_o + c * 8); }
+            }
+        }
+        if (half == 0 && ht < 32) plse = q0 + ht < Tn ? lse[(size_t)bh * Tn + q0 + ht] : 1.0e30f;      // rows beyond Tn: P = exp2(. - 1e30) = 0
+    };
+    auto commit = [&](int buf) {                       // registers -> LDS slice `buf`
+        unsigned char* dst = (half == 0 ? Qs : dOs) + buf * 32 * ROWB;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = ht + it * 256, r = idx / CH, c = idx - r * CH;
+            if (idx < 32 * CH) {
+                *reinterpret_cast<uint4*>(dst + ab_off<HD>(r, c)) = pa[it];
+                if (half == 1) {
+                    const unsigned x[4] = {pa[it].x, pa[it].y, pa[it].z, pa[it].w}, y[4] = {pb[it].x, pb[it].y, pb[it].z, pb[it].w};
+                    float dl = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        dl += __uint_as_float(x[e] << 16) * __uint_as_float(y[e] << 16) + __uint_as_float(x[e] & 0xffff0000u) * __uint_as_float(y[e] & 0xffff0000u);
+                    atomicAdd(&dlt_s[buf * 32 + r], dl);
+                }
+            }
+        }
+        if (half == 0 && ht < 32) lse_s[buf * 32 + ht] = plse;
+    };
+    if (!C::SWZ) {                                      // HD = 80: the pad columns (elements 80 .. 95) of both slice buffers are read as zeros
+        for (int idx = tid; idx < 2 * 2 * 32 * 2; idx += 512) {
+            const int which = idx >> 7, r = (idx >> 1) & 63, c = CH + (idx & 1);
+            *reinterpret_cast<uint4*>((which ? dOs : Qs) + r * ROWB + c * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (tid < 64) dlt_s[tid] = 0.f;
+    // dS columns of key tiles that are not in use are never written but can be read by the last 32-key step of dQ (against zero K rows)
+    for (int idx = tid; idx < 32 * AB_DS_STRIDE / 8; idx += 512) reinterpret_cast<uint4*>(dSs)[idx] = make_uint4(0, 0, 0, 0);
+    prefetch(0);
+    __syncthreads();
+    commit(0);
+    const int nstep = (Tn + 31) >> 5;
+    // transposing-read lane constants: lane (g, q4 = fr >> 2, p4 = lane & 3) supplies row 4g + q4 of a 16-row group, 8 bytes at p4*8 of a 32-byte block
+    const int q4 = fr >> 2, p4 = lane & 3;
+    for (int st = 0; st < nstep; ++st) {
+        const int q0 = st * 32, buf = st & 1;
+        if (st + 1 < nstep) prefetch(q0 + 32);
+        __syncthreads();                               // slice `buf` (Q, dO, lse, delta) is complete; the previous step's dS readers are done
+        if (tid < 32) dlt_s[(buf ^ 1) * 32 + tid] = 0.f;            // the other buffer's delta is re-accumulated by the next commit
+        const unsigned qs0 = lds0 + (unsigned)(Qs - sm) + buf * 32 * ROWB, ds0 = lds0 + (unsigned)(dOs - sm) + buf * 32 * ROWB;
+        unsigned pp[2][4], ds[2][4];                   // [key tile][packed bf16 pairs]: slots j < 4 from q-tile 0, j >= 4 from q-tile 1
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int tile = wave + 8 * kk;
+            if (tile >= nkt) { pp[kk][0] = pp[kk][1] = pp[kk][2] = pp[kk][3] = 0; ds[kk][0] = ds[kk][1] = ds[kk][2] = ds[kk][3] = 0; continue; }   // wave-uniform
+            const int key = tile * 16 + fr;
+            float pv[2][4], dsv[2][4];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, dpacc = sacc;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const uint4 qa = *reinterpret_cast<const uint4*>(Qs + buf * 32 * ROWB + ab_off<HD>(qt * 16 + fr, s * 4 + g));
+                    const uint4 da = *reinterpret_cast<const uint4*>(dOs + buf * 32 * ROWB + ab_off<HD>(qt * 16 + fr, s * 4 + g));
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qa), __builtin_bit_cast(bf16x8, kf[kk][s]), sacc, 0, 0, 0);
+                    dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, da), __builtin_bit_cast(bf16x8, vf[kk][s]), dpacc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = qt * 16 + g * 4 + r;
+                    const float p = key < nkeys ? __builtin_amdgcn_exp2f(sacc[r] * c2 - lse_s[buf * 32 + ql]) : 0.f;
+                    pv[qt][r] = p;
+                    dsv[qt][r] = p * (dpacc[r] - dlt_s[buf * 32 + ql]);
+                    dSs[ql * AB_DS_STRIDE + key] = f32_to_bf16_bits(dsv[qt][r]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                pp[kk][e] = (unsigned)f32_to_bf16_bits(pv[0][2 * e]) | ((unsigned)f32_to_bf16_bits(pv[0][2 * e + 1]) << 16);
+                pp[kk][2 + e] = (unsigned)f32_to_bf16_bits(pv[1][2 * e]) | ((unsigned)f32_to_bf16_bits(pv[1][2 * e + 1]) << 16);
+                ds[kk][e] = (unsigned)f32_to_bf16_bits(dsv[0][2 * e]) | ((unsigned)f32_to_bf16_bits(dsv[0][2 * e + 1]) << 16);
+                ds[kk][2 + e] = (unsigned)f32_to_bf16_bits(dsv[1][2 * e]) | ((unsigned)f32_to_bf16_bits(dsv[1][2 * e + 1]) << 16);
+            }
+        }
+        // dV^T += dO^T . P ; dK^T += Q^T . dS   (contraction over the 32 queries of the step: slot (g, u, j) <-> query 16u + 4g + j)
+        if (wave < nkt) {
+            // all transposing reads of the step first (one wait), then the MFMAs: block dt (32 bytes = 16 d) of rows 4g + q4 (+16); the
+            // swizzle moves whole 32-byte blocks, so the 8-byte piece p4 stays in place
+            u32x2 dfr[DT][2], qfr[DT][2];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                unsigned offa, offb;
+                if (C::SWZ) { const int r0 = 4 * g + q4; offa = (unsigned)(r0 * 128 + ((dt ^ ((r0 >> 1) & 3)) << 5) + p4 * 8); offb = (unsigned)((r0 + 16) * 128 + ((dt ^ (((r0 + 16) >> 1) & 3)) << 5) + p4 * 8); }
+                else { offa = (unsigned)((4 * g + q4) * ROWB + dt * 32 + p4 * 8); offb = offa + 16 * ROWB; }
+                dfr[dt][0] = ab_tr_read(ds0 + offa); dfr[dt][1] = ab_tr_read(ds0 + offb); qfr[dt][0] = ab_tr_read(qs0 + offa); qfr[dt][1] = ab_tr_read(qs0 + offb);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const u32x4 da = (u32x4){dfr[dt][0][0], dfr[dt][0][1], dfr[dt][1][0], dfr[dt][1][1]}, qa = (u32x4){qfr[dt][0][0], qfr[dt][0][1], qfr[dt][1][0], qfr[dt][1][1]};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    if (wave + 8 * kk >= nkt) continue;
+                    const u32x4 pbv = (u32x4){pp[kk][0], pp[kk][1], pp[kk][2], pp[kk][3]}, sbv = (u32x4){ds[kk][0], ds[kk][1], ds[kk][2], ds[kk][3]};
+                    dvacc[dt][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, da), __builtin_bit_cast(bf16x8, pbv), dvacc[dt][kk], 0, 0, 0);
+                    dkacc[dt][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qa), __builtin_bit_cast(bf16x8, sbv), dkacc[dt][kk], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                               // dS of every key tile in use is in LDS
+        if (st + 1 < nstep) commit(buf ^ 1);           // next slice: its buffer was last read in step st-1
+        // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]: 2 q tiles x DT d tiles, dealt round-robin to the 8 waves
+        for (int pr = wave; pr < 2 * DT; pr += 8) {
+            const int qt = pr / DT, dt = pr - qt * DT;
+            f32x4 qacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int nks = (nkeys + 31) >> 5;
+            for (int ks0 = 0; ks0 < nks; ks0 += 4) {   // four 32-key steps per wait (steps beyond the block read zero K rows: harmless)
+                u32x2 kr[4][2]; uint2 sr[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = ks0 + u < 8 ? ks0 + u : 7;
+                    const int r0 = ks * 32 + 4 * g + q4;
+                    unsigned offa, offb;
+                    if (C::SWZ) { offa = (unsigned)(r0 * 128 + ((dt ^ ((r0 >> 1) & 3)) << 5) + p4 * 8); offb = (unsigned)((r0 + 16) * 128 + ((dt ^ (((r0 + 16) >> 1) & 3)) << 5) + p4 * 8); }
+                    else { offa = (unsigned)(r0 * ROWB + dt * 32 + p4 * 8); offb = offa + 16 * ROWB; }
+                    kr[u][0] = ab_tr_read(lds0 + offa); kr[u][1] = ab_tr_read(lds0 + offb);
+                    sr[u][0] = *reinterpret_cast<const uint2*>(dSs + (qt * 16 + fr) * AB_DS_STRIDE + ks * 32 + 4 * g);
+                    sr[u][1] = *reinterpret_cast<const uint2*>(dSs + (qt * 16 + fr) * AB_DS_STRIDE + ks * 32 + 16 + 4 * g);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ks0 + u >= nks) continue;
+                    const u32x4 ka = (u32x4){kr[u][0][0], kr[u][0][1], kr[u][1][0], kr[u][1][1]}, sbv = (u32x4){sr[u][0].x, sr[u][0].y, sr[u][1].x, sr[u][1].y};
+                    qacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, sbv), qacc, 0, 0, 0);
+                }
+            }
+            const int q = q0 + qt * 16 + fr;           // D rows = d (4g + e), column = query fr
+            if (q < Tn) {
+                if (gridDim.y == 1) {
+                    uint2 ov;
+                    ov.x = (unsigned)f32_to_bf16_bits(qacc[0] * scale) | ((unsigned)f32_to_bf16_bits(qacc[1] * scale) << 16);
+                    ov.y = (unsigned)f32_to_bf16_bits(qacc[2] * scale) | ((unsigned)f32_to_bf16_bits(qacc[3] * scale) << 16);
+                    *reinterpret_cast<uint2*>(dqkv + ((size_t)b * Tn + q) * ld_qkv + (size_t)h * HD + dt * 16 + g * 4) = ov;
+                } else {
+                    float* ap = dq_accum + ((size_t)b * Tn + q) * D + (size_t)h * HD + dt * 16 + g * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(ap + e, qacc[e] * scale);
+                }
+            }
+        }
+        // (the next iteration's first barrier separates these dS reads from the next step's dS writes)
+    }
+    // ---- dK, dV of this wave's keys: lane holds 4 consecutive d of one key
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int key = (wave + 8 * kk) * 16 + fr;
+        if (key >= nkeys) continue;
+        unsigned short* dkrow = dqkv + ((size_t)b * Tn + key0 + key) * ld_qkv + D + (size_t)h * HD;
+        unsigned short* dvrow = dqkv + ((size_t)b * Tn + key0 + key) * ld_qkv + 2 * D + (size_t)h * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            uint2 kk2, vv;
+            kk2.x = (unsigned)f32_to_bf16_bits(dkacc[dt][kk][0] * scale) | ((unsigned)f32_to_bf16_bits(dkacc[dt][kk][1] * scale) << 16);
+            kk2.y = (unsigned)f32_to_bf16_bits(dkacc[dt][kk][2] * scale) | ((unsigned)f32_to_bf16_bits(dkacc[dt][kk][3] * scale) << 16);
+            vv.x = (unsigned)f32_to_bf16_bits(dvacc[dt][kk][0]) | ((unsigned)f32_to_bf16_bits(dvacc[dt][kk][1]) << 16);
+            vv.y = (unsigned)f32_to_bf16_bits(dvacc[dt][kk][2]) | ((unsigned)f32_to_bf16_bits(dvacc[dt][kk][3]) << 16);
+            *reinterpret_cast<uint2*>(dkrow + dt * 16 + g * 4) = kk2;
+            *reinterpret_cast<uint2*>(dvrow + dt * 16 + g * 4) = vv;
+        }
+    }
+}
+
+// several key blocks: dq (bf16, the q columns of dqkv) = the f32 sums of their parts
+__global__ void attention_dq_finish_kernel(const float* __restrict__ acc, unsigned short* __restrict__ dqkv, long long rows, int D, long long ld_qkv) {
+    const long long n = rows * (D / 4);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / (D / 4); const int c = (int)(i - r * (D / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(acc + r * D + c);
+        uint2 ov;
+        ov.x = (unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16);
+        ov.y = (unsigned)f32_to_bf16_bits(v.z) | ((unsigned)f32_to_bf16_bits(v.w) << 16);
+        *reinterpret_cast<uint2*>(dqkv + r * ld_qkv + c) = ov;
+    }
+}
+
+template <int HD>
+int launch_attention_bwd2(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* dq_accum, int64_t B, int64_t T, int64_t H,
+                          int64_t ld_qkv, int64_t ld_o, float scale, hipStream_t s) {
+    using C = AbCfg<HD>;
+    const size_t shm = (size_t)AB_KEYS * C::ROWB + 4 * 32 * C::ROWB + 32 * AB_DS_STRIDE * 2 + 128 * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)attention_bwd2_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) { occ_set_error("occ_attention_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+    const int64_t nkb = occ_cdiv(T, AB_KEYS);
+    if (nkb > 1 && hipMemsetAsync(dq_accum, 0, (size_t)(B * T * H * HD) * sizeof(float), s) != hipSuccess) { occ_set_error("occ_attention_bwd: memset failed"); return OCC_ELAUNCH; }
+    hipLaunchKernelGGL(attention_bwd2_kernel<HD>, dim3((unsigned)(B * H), (unsigned)nkb), dim3(512), shm, s, (const unsigned short*)qkv, (const unsigned short*)o,
+                       (const unsigned short*)dout, lse, (unsigned short*)dqkv, dq_accum, (int)T, (int)H, (long long)ld_qkv, (long long)ld_o, scale);
+    if (nkb > 1) {
+        long long blocks = occ_cdiv(B * T * (H * HD / 4), 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(attention_dq_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dq_accum, (unsigned short*)dqkv, (long long)(B * T), (int)(H * HD), (long long)ld_qkv);
+    }
+    return OCC_OK;
+}
+
+}  // namespace
+
+extern "C" int occ_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H, int64_t hd,
+                                 int64_t ld_qkv, int64_t ld_o, float scale, float* dq_accum, void* stream) {
+    OCC_CHECK_ARG(qkv && o && dout && lse && dqkv, "occ_attention_bwd: null pointer");
+    OCC_CHECK_ARG((hd == 64 || hd == 80) && T >= 1 && B >= 1 && H >= 1 && B * H < (1ll << 31) && T < (1ll << 24), "occ_attention_bwd: head_dim must be 64 or 80 (T=%ld hd=%ld)", (long)T, (long)hd);
+    OCC_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_qkv >= 3 * H * hd && ld_o >= H * hd, "occ_attention_bwd: leading dimensions");
+    OCC_CHECK_ARG(T <= AB_KEYS || (dq_accum && ((uintptr_t)dq_accum & 15) == 0), "occ_attention_bwd: T > %d needs the f32 dq accumulator [B*T, H*hd]", AB_KEYS);
+    int rc;
+    if (hd == 64) rc = launch_attention_bwd2<64>(qkv, o, dout, lse, dqkv, dq_accum, B, T, H, ld_qkv, ld_o, scale, (hipStream_t)stream);
+    else rc = launch_attention_bwd2<80>(qkv, o, dout, lse, dqkv, dq_accum, B, T, H, ld_qkv, ld_o, scale, (hipStream_t)stream);
+    if (rc != OCC_OK) return rc;
+    OCC_LAUNCH_CHECK("occ_attention_bwd");
+    return OCC_OK;
+}

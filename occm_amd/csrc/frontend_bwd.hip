@@ -194,182 +194,140 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Attention backward, head_dim 64, T <= 256, one workgroup (4 waves) per (batch, head).
-// Keys are partitioned over the waves (64 each) and live on the MFMA lane, so S[q][key] and dP[q][key] come out of the
-// MFMA already shaped as the B operands of dV^T += dO^T.P and dK^T += Q^T.dS (each wave keeps dK^T/dV^T of its keys in
-// registers over the whole query sweep).  Probabilities are rebuilt from the forward's log-sum-exp (no row reductions), the
-// row term delta = rowsum(dO * O) is computed in the prologue, and only dS crosses LDS, once per 32-query step, for dQ.
-constexpr int AB_TP = 256;             // padded sequence length
-constexpr int AB_TS = AB_TP + 8;       // row stride (elements) of the transposed / dS LDS images: 16-byte aligned rows
-
-__global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ o,
-                                                              const unsigned short* __restrict__ dout, const float* __restrict__ lse,
-                                                              unsigned short* __restrict__ dqkv, int Tn, int H, long long ld_qkv, long long ld_o,
-                                                              float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
-    unsigned short* Qt = sm;                         // [64][AB_TS]  Q^T
-    unsigned short* dOt = Qt + 64 * AB_TS;           // [64][AB_TS]  dO^T
-    unsigned short* Kt = dOt + 64 * AB_TS;           // [64][AB_TS]  K^T
-    unsigned short* dSs = Kt + 64 * AB_TS;           // [32][AB_TS]  dS of the current 32-query step
-    float* lse_s = reinterpret_cast<float*>(dSs + 32 * AB_TS);   // [AB_TP]
-    float* dlt_s = lse_s + AB_TP;                                // [AB_TP]
-    const int D = H * 64;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const unsigned short* base = qkv + (size_t)b * Tn * ld_qkv + (size_t)h * 64;
-    const unsigned short* obase = o + (size_t)b * Tn * ld_o + (size_t)h * 64;
-    const unsigned short* dobase = dout + (size_t)b * Tn * ld_o + (size_t)h * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
-
-    // ---- prologue: transposed images (zero beyond Tn), lse and delta ----
-    for (int idx = tid; idx < AB_TP * 8; idx += 256) {
-        const int t = idx >> 3, ch = idx & 7;
-        uint4 qv = make_uint4(0, 0, 0, 0), dv = qv, kv = qv;
-        if (t < Tn) {
-            qv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld_qkv + ch * 8);
-            kv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld_qkv + D + ch * 8);
-            dv = *reinterpret_cast<const uint4*>(dobase + (size_t)t * ld_o + ch * 8);
-        }
-        const unsigned qw[4] = {qv.x, qv.y, qv.z, qv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w}, kw[4] = {kv.x, kv.y, kv.z, kv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            Qt[(ch * 8 + 2 * e) * AB_TS + t] = (unsigned short)(qw[e] & 0xffff); Qt[(ch * 8 + 2 * e + 1) * AB_TS + t] = (unsigned short)(qw[e] >> 16);
-            dOt[(ch * 8 + 2 * e) * AB_TS + t] = (unsigned short)(dw[e] & 0xffff); dOt[(ch * 8 + 2 * e + 1) * AB_TS + t] = (unsigned short)(dw[e] >> 16);
-            Kt[(ch * 8 + 2 * e) * AB_TS + t] = (unsigned short)(kw[e] & 0xffff); Kt[(ch * 8 + 2 * e + 1) * AB_TS + t] = (unsigned short)(kw[e] >> 16);
-        }
+// Sixteen-wave form of the kernel above (4 waves per SIMD on one workgroup per CU).  The row loop is a chain of four dependent wave
+// reductions, so a wave alone on its SIMD runs at that latency (measured: 94 us for 12736 x 1024 = 2.2 TB/s); more waves per SIMD hide
+// it, but more WORKGROUPS would multiply the dgamma / dbeta atomics on the same 2C addresses.  Here the per-column sums live in LDS
+// (ds_add_f32 from all 16 waves, lane-contiguous layout: no bank conflicts) instead of 32 registers per lane, which is what lets
+// the wave fit 128 registers; the workgroup still issues one set of global atomics at the end.
+template <typename TDY, typename TX, int NIT, bool GELU>
+__global__ __launch_bounds__(1024) void layernorm_bwd16_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ dres, float* __restrict__ dx,
+                                                              unsigned short* __restrict__ dx_bf16, RowMapI bmap, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, long long rows, int C, float eps, float* __restrict__ partials) {
+    __shared__ float accg[8 * NIT * 64], accb[8 * NIT * 64];     // [element e of the lane's 8][it*64 + lane]
+    __shared__ __attribute__((aligned(16))) float gs[NIT * 512], bs[GELU ? NIT * 512 : 4];   // gamma / beta: read from LDS at each use (register budget)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 8 * NIT * 64; i += 1024) {
+        accg[i] = 0.f; accb[i] = 0.f;
+        gs[i] = i < C ? gamma[i] : 0.f;
+        if (GELU) bs[i] = i < C ? beta[i] : 0.f;
     }
-    for (int t = tid; t < AB_TP; t += 256) {
-        float dl = 0.f, ls = 1.0e30f;                    // rows beyond Tn: P = exp2(. - 1e30) = 0
-        if (t < Tn) {
-            ls = lse[(size_t)bh * Tn + t];
-            for (int d = 0; d < 64; ++d) dl += bf16_bits_to_f32(dobase[(size_t)t * ld_o + d]) * bf16_bits_to_f32(obase[(size_t)t * ld_o + d]);
-        }
-        lse_s[t] = ls; dlt_s[t] = dl;
-    }
-    // ---- this wave's keys: K and V row fragments stay in registers ----
-    uint4 kf[4][2], vf[4][2];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        const int key = wave * 64 + kt * 16 + fr;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            kf[kt][s] = make_uint4(0, 0, 0, 0); vf[kt][s] = kf[kt][s];
-            if (key < Tn) {
-                kf[kt][s] = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + D + s * 32 + g * 8);
-                vf[kt][s] = *reinterpret_cast<const uint4*>(base + (size_t)key * ld_qkv + 2 * D + s * 32 + g * 8);
-            }
-        }
-    }
-    f32x4 dvacc[4][4], dkacc[4][4];                   // [d-tile][key-tile]: rows d = 16*dt + 4g + r, col key = 16*kt + fr
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { dvacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkacc[i][j] = dvacc[i][j]; }
-    const float c2 = scale * 1.44269504088896340736f;
     __syncthreads();
-
-    const int nstep = (Tn + 31) / 32;
-    for (int st = 0; st < nstep; ++st) {
-        const int q0 = st * 32;
-        // Q / dO row fragments of the two 16-query tiles (A operands), straight from global (L2-resident)
-        uint4 qf[2][2], df[2][2];
+    const long long wave0 = (long long)blockIdx.x * 16 + wave, nwaves = (long long)gridDim.x * 16;
+    float dg[NIT][8], db[NIT][8];                  // per-lane column sums over this wave's rows (LDS float atomics per row measured 2.5x slower)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int q = q0 + qt * 16 + fr;
+    for (int it = 0; it < NIT; ++it)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                qf[qt][s] = make_uint4(0, 0, 0, 0); df[qt][s] = qf[qt][s];
-                if (q < Tn) {
-                    qf[qt][s] = *reinterpret_cast<const uint4*>(base + (size_t)q * ld_qkv + s * 32 + g * 8);
-                    df[qt][s] = *reinterpret_cast<const uint4*>(dobase + (size_t)q * ld_o + s * 32 + g * 8);
+        for (int e = 0; e < 8; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; }
+    // no next-row prefetch here: with four waves per SIMD the other waves cover the load latency, and the 24 registers decide whether
+    // the kernel fits the 128-register budget of a 16-wave workgroup
+    for (long long row = wave0; row < rows; row += nwaves) {
+        float xv[NIT][8], dv[NIT][8];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xv[it][e] = 0.f; dv[it][e] = 0.f; }
+            if (c < C) { LVec8<TX>::load(x + row * C + c, xv[it]); LVec8<TDY>::load(dy + row * C + c, dv[it]); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += xv[it][e];
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 8;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = xv[it][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (xv[it][e] - mean) * rstd;
+                const float ge = gs[(it * 64 + lane) * 8 + e];
+                if (GELU) dv[it][e] *= gelu_grad(xh * ge + bs[GELU ? (it * 64 + lane) * 8 + e : 0]);
+                const float dxh = dv[it][e] * ge;
+                xv[it][e] = xh;
+                s1 += dxh; s2 += dxh * xh;
+                dg[it][e] += dv[it][e] * xh; db[it][e] += dv[it][e];
+            }
+        s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 8;
+            if (c < C) {
+                float v[8], r[8];
+                if (dres) LVec8<float>::load(dres + row * C + c, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = rstd * (dv[it][e] * gs[c + e] - s1 - xv[it][e] * s2);
+                    if (dres) v[e] += r[e];
+                }
+                if (dx) {
+                    *reinterpret_cast<float4*>(dx + row * C + c) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dx + row * C + c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                if (dx_bf16) {
+                    unsigned w[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+                    *reinterpret_cast<uint4*>(dx_bf16 + row_off(bmap, row) + c) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
         }
-        unsigned pp[4][4], ds[4][4];                   // [key-tile][packed bf16 pairs]: slots j<4 from q-tile 0, j>=4 from q-tile 1
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const int key = wave * 64 + kt * 16 + fr;
-            float pv[2][4], dsv[2][4];
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, dpacc = sacc;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&qf[qt][s]), *reinterpret_cast<bf16x8*>(&kf[kt][s]), sacc, 0, 0, 0);
-                    dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&df[qt][s]), *reinterpret_cast<bf16x8*>(&vf[kt][s]), dpacc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = q0 + qt * 16 + g * 4 + r;
-                    const float p = key < Tn ? __builtin_amdgcn_exp2f(sacc[r] * c2 - lse_s[q]) : 0.f;
-                    pv[qt][r] = p;
-                    dsv[qt][r] = p * (dpacc[r] - dlt_s[q]);
-                    dSs[(qt * 16 + g * 4 + r) * AB_TS + key] = f32_to_bf16_bits(dsv[qt][r]);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                pp[kt][e] = (unsigned)f32_to_bf16_bits(pv[0][2 * e]) | ((unsigned)f32_to_bf16_bits(pv[0][2 * e + 1]) << 16);
-                pp[kt][2 + e] = (unsigned)f32_to_bf16_bits(pv[1][2 * e]) | ((unsigned)f32_to_bf16_bits(pv[1][2 * e + 1]) << 16);
-                ds[kt][e] = (unsigned)f32_to_bf16_bits(dsv[0][2 * e]) | ((unsigned)f32_to_bf16_bits(dsv[0][2 * e + 1]) << 16);
-                ds[kt][2 + e] = (unsigned)f32_to_bf16_bits(dsv[1][2 * e]) | ((unsigned)f32_to_bf16_bits(dsv[1][2 * e + 1]) << 16);
-            }
-        }
-        // dV^T += dO^T . P ; dK^T += Q^T . dS   (k = the 32 queries of this step, slot j <-> q0 + (j<4 ? 4g+j : 16+4g+j-4))
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const unsigned short* dr = dOt + (dt * 16 + fr) * AB_TS + q0 + g * 4;
-            const unsigned short* qr = Qt + (dt * 16 + fr) * AB_TS + q0 + g * 4;
-            const uint2 d0 = *reinterpret_cast<const uint2*>(dr), d1 = *reinterpret_cast<const uint2*>(dr + 16);
-            const uint2 q0v = *reinterpret_cast<const uint2*>(qr), q1v = *reinterpret_cast<const uint2*>(qr + 16);
-            uint4 da = make_uint4(d0.x, d0.y, d1.x, d1.y), qa = make_uint4(q0v.x, q0v.y, q1v.x, q1v.y);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                uint4 pb = make_uint4(pp[kt][0], pp[kt][1], pp[kt][2], pp[kt][3]);
-                uint4 sb = make_uint4(ds[kt][0], ds[kt][1], ds[kt][2], ds[kt][3]);
-                dvacc[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&da), *reinterpret_cast<bf16x8*>(&pb), dvacc[dt][kt], 0, 0, 0);
-                dkacc[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&qa), *reinterpret_cast<bf16x8*>(&sb), dkacc[dt][kt], 0, 0, 0);
-            }
-        }
-        __syncthreads();                               // dS of all 256 keys is in LDS
-        // dQ[q][d] = scale * sum_key dS[q][key] K[key][d]: wave w owns d-tile w, all keys
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            f32x4 qacc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < AB_TP / 32; ++ks) {
-                uint4 af = *reinterpret_cast<const uint4*>(dSs + (qt * 16 + fr) * AB_TS + ks * 32 + g * 8);
-                uint4 bfv = *reinterpret_cast<const uint4*>(Kt + (wave * 16 + fr) * AB_TS + ks * 32 + g * 8);
-                qacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&af), *reinterpret_cast<bf16x8*>(&bfv), qacc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = q0 + qt * 16 + g * 4 + r;
-                if (q < Tn) dqkv[((size_t)b * Tn + q) * ld_qkv + (size_t)h * 64 + wave * 16 + fr] = f32_to_bf16_bits(qacc[r] * scale);
-            }
-        }
-        __syncthreads();                               // dSs is rewritten by the next step
     }
-    // ---- dK, dV of this wave's keys: lane holds 4 consecutive d of one key ----
+    // the sixteen waves add their sums into the LDS arrays one after the other (fixed order), then one set of global atomics
+    for (int w = 0; w < 16; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        const int key = wave * 64 + kt * 16 + fr;
-        if (key >= Tn) continue;
-        unsigned short* dkrow = dqkv + ((size_t)b * Tn + key) * ld_qkv + D + (size_t)h * 64;
-        unsigned short* dvrow = dqkv + ((size_t)b * Tn + key) * ld_qkv + 2 * D + (size_t)h * 64;
+            for (int it = 0; it < NIT; ++it)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            uint2 kk, vv;
-            kk.x = (unsigned)f32_to_bf16_bits(dkacc[dt][kt][0] * scale) | ((unsigned)f32_to_bf16_bits(dkacc[dt][kt][1] * scale) << 16);
-            kk.y = (unsigned)f32_to_bf16_bits(dkacc[dt][kt][2] * scale) | ((unsigned)f32_to_bf16_bits(dkacc[dt][kt][3] * scale) << 16);
-            vv.x = (unsigned)f32_to_bf16_bits(dvacc[dt][kt][0]) | ((unsigned)f32_to_bf16_bits(dvacc[dt][kt][1]) << 16);
-            vv.y = (unsigned)f32_to_bf16_bits(dvacc[dt][kt][2]) | ((unsigned)f32_to_bf16_bits(dvacc[dt][kt][3]) << 16);
-            *reinterpret_cast<uint2*>(dkrow + dt * 16 + g * 4) = kk;
-            *reinterpret_cast<uint2*>(dvrow + dt * 16 + g * 4) = vv;
+                for (int e = 0; e < 8; ++e) { accg[e * (NIT * 64) + it * 64 + lane] += dg[it][e]; accb[e * (NIT * 64) + it * 64 + lane] += db[it][e]; }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 8 * NIT * 64; i += 1024) {
+        const int e = i / (NIT * 64), l = i - e * (NIT * 64), c = l * 8 + e;
+        if (c < C) {
+            // 256 workgroups adding to the same 2C addresses cost ~25 us of a 77 us launch: with caller scratch the sums go out as
+            // plain stores [block][2][C] and layernorm_bwd_finalize_kernel adds them up in block order
+            if (partials) { partials[((long long)blockIdx.x * 2) * C + c] = accg[i]; partials[((long long)blockIdx.x * 2 + 1) * C + c] = accb[i]; }
+            else { atomicAdd(dgamma + c, accg[i]); atomicAdd(dbeta + c, accb[i]); }
         }
     }
 }
 
+// 64 columns per workgroup; the four waves take every fourth block (independent loads, eight in flight), wave 0 adds the four sums
+__global__ __launch_bounds__(256) void layernorm_bwd_finalize_kernel(const float* __restrict__ partials, int nblocks, int C, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;                  // [2][C]
+    float s = 0.f;
+    if (i < 2 * C) {
+        int b = wave;
+        for (; b + 28 < nblocks; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(long long)(b + 4 * u) * 2 * C + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblocks; b += 4) s += partials[(long long)b * 2 * C + i];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && i < 2 * C) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (i < C) dgamma[i] += t; else dbeta[i - C] += t;
+    }
+}
 
 // out[omap(r)][c] = bf16(dy[r][c] * gelu'(u[r][c]))   (gradient through the positional conv's GELU, written into the padded buffer)
 __global__ void gelu_bwd_rows_kernel(const float* __restrict__ dy, const unsigned short* __restrict__ u, unsigned short* __restrict__ out, RowMapI omap,
@@ -559,7 +517,7 @@ int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, 
 
 int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta, const float* dres, float* dx,
                          void* dx_bf16, const occ_rowmap* dx_bf16_map, float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, int gelu,
-                         void* stream) {
+                         float* scratch, int64_t scratch_floats, void* stream) {
     OCC_CHECK_ARG(dy && x && gamma && (dx || dx_bf16) && dgamma && dbeta, "occ_layernorm_bwd: null pointer");
     OCC_CHECK_ARG(!gelu || beta, "occ_layernorm_bwd: the fused GELU needs beta");
     OCC_CHECK_ARG(rows >= 1 && C >= 8 && C % 8 == 0 && C <= 2048, "occ_layernorm_bwd: C must be a multiple of 8 in [8,2048]");
@@ -574,7 +532,14 @@ int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
     RowMapI bm = occ_make_rowmap(rows, 0, C, 0, 0);
     if (dx_bf16_map) { OCC_CHECK_ARG(dx_bf16_map->rows_per_batch >= 1 && dx_bf16_map->row_stride % 8 == 0 && dx_bf16_map->batch_stride % 8 == 0, "occ_layernorm_bwd: bad bf16 row map"); bm = to_rowmap(*dx_bf16_map); }
 #define OCC_LNB(TD, TXX, N, G) hipLaunchKernelGGL((layernorm_bwd_kernel<TD, TXX, N, G>), dim3((unsigned)blocks), dim3(256), 0, s, (const TD*)dy, (const TXX*)x, gamma, beta, dres, dx, (unsigned short*)dx_bf16, bm, dgamma, dbeta, (long long)rows, (int)C, eps)
-#define OCC_LNB_N(TD, TXX, G) do { if (nit == 1) OCC_LNB(TD, TXX, 1, G); else if (nit == 2) OCC_LNB(TD, TXX, 2, G); else if (nit == 3) OCC_LNB(TD, TXX, 3, false); else OCC_LNB(TD, TXX, 4, false); } while (0)
+#define OCC_LNB16(TD, TXX, N, G) hipLaunchKernelGGL((layernorm_bwd16_kernel<TD, TXX, N, G>), dim3((unsigned)blocks16), dim3(1024), 0, s, (const TD*)dy, (const TXX*)x, gamma, beta, dres, dx, (unsigned short*)dx_bf16, bm, dgamma, dbeta, (long long)rows, (int)C, eps, part)
+    static const int lnb16 = getenv("OCC_LNB16") ? atoi(getenv("OCC_LNB16")) : 1;
+    long long blocks16 = occ_cdiv(rows, 16 * 4);        // >= 4 rows per wave
+    if (blocks16 > lnb_blocks) blocks16 = lnb_blocks;
+    const bool wide = lnb16 && rows >= 2048 && !(gelu && nit == 2) && nit <= 2;      // (the GELU form at C > 512 does not fit 128 registers)
+    float* part = wide && scratch && scratch_floats >= blocks16 * 2 * C && ((uintptr_t)scratch & 15) == 0 ? scratch : nullptr;
+#define OCC_LNB_N(TD, TXX, G) do { if (nit == 1) { if (wide) OCC_LNB16(TD, TXX, 1, G); else OCC_LNB(TD, TXX, 1, G); } else if (nit == 2) { if (wide) OCC_LNB16(TD, TXX, 2, G); else OCC_LNB(TD, TXX, 2, G); } \
+                                   else if (nit == 3) OCC_LNB(TD, TXX, 3, false); else OCC_LNB(TD, TXX, 4, false); } while (0)
     const bool df = dy_dtype == OCC_F32, xf = x_dtype == OCC_F32;
     if (gelu) {
         if (df && xf) OCC_LNB_N(float, float, true); else if (df) OCC_LNB_N(float, unsigned short, true);
@@ -584,28 +549,16 @@ int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
         else if (xf) OCC_LNB_N(unsigned short, float, false); else OCC_LNB_N(unsigned short, unsigned short, false);
     }
 #undef OCC_LNB_N
+#undef OCC_LNB16
 #undef OCC_LNB
+    if (part) hipLaunchKernelGGL(layernorm_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(2 * C, 64)), dim3(256), 0, s, part, (int)blocks16, (int)C, dgamma, dbeta);
     OCC_LAUNCH_CHECK("occ_layernorm_bwd");
     return OCC_OK;
 }
 
 int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
-                      float* dbeta, int64_t rows, int64_t C, float eps, void* stream) {
-    return occ_layernorm_bwd_ex(dy, dy_dtype, x, OCC_F32, gamma, nullptr, dres, dx, dx_bf16, nullptr, dgamma, dbeta, rows, C, eps, 0, stream);
-}
-
-int occ_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H, int64_t hd,
-                      int64_t ld_qkv, int64_t ld_o, float scale, void* stream) {
-    OCC_CHECK_ARG(qkv && o && dout && lse && dqkv, "occ_attention_bwd: null pointer");
-    OCC_CHECK_ARG(hd == 64 && T >= 1 && T <= AB_TP && B >= 1 && H >= 1, "occ_attention_bwd: needs head_dim 64 and T <= %d (T=%ld hd=%ld)", AB_TP, (long)T, (long)hd);
-    OCC_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_qkv >= 3 * H * hd && ld_o >= H * hd, "occ_attention_bwd: leading dimensions");
-    const size_t shm = (size_t)(3 * 64 + 32) * AB_TS * 2 + 2 * AB_TP * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (e != hipSuccess) { occ_set_error("occ_attention_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3((unsigned)(B * H)), dim3(256), shm, (hipStream_t)stream, (const unsigned short*)qkv, (const unsigned short*)o,
-                       (const unsigned short*)dout, lse, (unsigned short*)dqkv, (int)T, (int)H, (long long)ld_qkv, (long long)ld_o, scale);
-    OCC_LAUNCH_CHECK("occ_attention_bwd");
-    return OCC_OK;
+                      float* dbeta, int64_t rows, int64_t C, float eps, float* scratch, int64_t scratch_floats, void* stream) {
+    return occ_layernorm_bwd_ex(dy, dy_dtype, x, OCC_F32, gamma, nullptr, dres, dx, dx_bf16, nullptr, dgamma, dbeta, rows, C, eps, 0, scratch, scratch_floats, stream);
 }
 
 int occ_gelu_bwd_rows(const float* dy, const void* u, void* out, const occ_rowmap* out_map, int64_t rows, int64_t C, void* stream) {

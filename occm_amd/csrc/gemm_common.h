@@ -201,6 +201,91 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Row-layout epilogue.  In the MFMA result layout a lane owns 4 consecutive columns of ONE row per accumulator, so a store instruction
+// of the epilogues above touches 16 rows with 32-64 bytes each; measured on the 256x256 kernel (scripts/diag_p8.hip) that store pattern
+// made the epilogue 18 k (bf16 out) to 36 k cycles (f32 out + f32 residual) per tile against 36.7 k cycles for a whole K = 1024 loop.
+// Here every wave sends its accumulators through a private LDS region in chunks of 32 rows x 64 columns (f32, 272-byte rows: the pad
+// keeps the 16-byte writes of 8 rows on disjoint banks) and reads them back with a ROW per 16 lanes, so that bias, side tensor,
+// residual and C are all accessed as whole contiguous row segments (64 columns = 256 B f32 / 128 B bf16, four rows per instruction).
+// lds_wave: >= 8704 bytes private to the calling wave, 16-byte aligned, not in use by anything else.
+template <int NJ, bool HASB, bool GELU, bool HASR, bool CBF, int AUXM>
+__device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int lane, unsigned char* lds_wave) {
+    static_assert(NJ % 2 == 0, "row epilogue works on pairs of 16-row blocks");
+    constexpr int RS = 272;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = lane >> 4, cc = lane & 15;                  // read-back: row rr (+4k) of the chunk, columns 4*cc .. 4*cc+3
+    const long long n = ncol0 + cc * 4;
+    const bool plain_c = a.cmap.rpl == 0 && a.cmap.rpb >= a.M, plain_r = !HASR || (a.rmap.rpl == 0 && a.rmap.rpb >= a.M);
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (HASB && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+    for (int ch = 0; ch < NJ / 2; ++ch) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<f32x4*>(lds_wave + (jj * 16 + fr) * RS + i * 64 + fq * 16) = acc[i][ch * 2 + jj];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(lds_wave + (k * 4 + rr) * RS + cc * 16);
+            const long long m = mrow0 + ch * 32 + k * 4 + rr;
+            if (m >= a.M || n >= a.N) continue;
+            const long long coff = (plain_c ? m * a.cmap.rstride : row_off(a.cmap, m)) + n;
+            if (HASB) v += bv;
+            if (AUXM == 1) {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2*>(a.aux + coff) = o;
+            }
+            if (AUXM == 2) {
+                const uint2 u = *reinterpret_cast<const uint2*>(a.aux + coff);
+                v[0] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x & 0xffff))); v[1] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x >> 16)));
+                v[2] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y & 0xffff))); v[3] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y >> 16)));
+            }
+            if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            if (HASR) v += *reinterpret_cast<const f32x4*>(a.R + ((plain_r ? m * a.rmap.rstride : row_off(a.rmap, m)) + n) * 4);
+            if (CBF) {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2*>(a.C + coff * 2) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(a.C + coff * 4) = v;
+            }
+        }
+    }
+}
+
+// Dispatcher: the combinations the front-end launches (no side tensor or one of the two fine-tuning forms; activation none / GELU;
+// residual none / f32) take the row-layout epilogue, anything else the generic one.  ncol0 / the wave's columns must lie inside one
+// 64-column span (true for every kernel of this family: a wave owns 64 output columns).
+template <int NJ>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int lane, long long cshift,
+                                                   unsigned char* lds_wave) {
+    const int fr = lane & 15, fq = lane >> 4;
+    if (cshift == 0 && a.alpha == 1.0f && (!a.R || a.r_dtype == OCC_F32)) {
+        if (a.aux && !a.R && a.c_dtype != OCC_F32) {
+            if (a.act == OCC_ACT_GELU && a.bias) { gemm_epilogue_rows_t<NJ, true, true, false, true, 1>(a, acc, mrow0, ncol0, lane, lds_wave); return; }
+            if (a.act == OCC_ACT_GELU_GRAD && !a.bias) { gemm_epilogue_rows_t<NJ, false, false, false, true, 2>(a, acc, mrow0, ncol0, lane, lds_wave); return; }
+        }
+        if (!a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU)) {
+            const int key = (a.bias ? 8 : 0) | (a.act == OCC_ACT_GELU ? 4 : 0) | (a.R ? 2 : 0) | (a.c_dtype != OCC_F32 ? 1 : 0);
+#define OCC_EPR(K, B, G, R, C) case K: gemm_epilogue_rows_t<NJ, B, G, R, C, 0>(a, acc, mrow0, ncol0, lane, lds_wave); break;
+            switch (key) {
+                OCC_EPR(0, false, false, false, false) OCC_EPR(1, false, false, false, true) OCC_EPR(2, false, false, true, false) OCC_EPR(3, false, false, true, true)
+                OCC_EPR(4, false, true, false, false) OCC_EPR(5, false, true, false, true) OCC_EPR(6, false, true, true, false) OCC_EPR(7, false, true, true, true)
+                OCC_EPR(8, true, false, false, false) OCC_EPR(9, true, false, false, true) OCC_EPR(10, true, false, true, false) OCC_EPR(11, true, false, true, true)
+                OCC_EPR(12, true, true, false, false) OCC_EPR(13, true, true, false, true) OCC_EPR(14, true, true, true, false) OCC_EPR(15, true, true, true, true)
+            }
+#undef OCC_EPR
+            return;
+        }
+    }
+    gemm_epilogue<NJ>(a, acc, mrow0, ncol0, fr, fq, cshift);
+}
+
 // MODE 0: f32 operands, exact-f32 MFMA.  MODE 1: bf16 operands, bf16 MFMA.  MODE 2: f32 operands in memory, rounded to
 // bf16 while they are staged into LDS, bf16 MFMA (f32 accumulate) -- the back-end's "bf16 compute" mode, which
 // needs no bf16 copies of f32 activations / gradients.

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
 #ifdef P8_DIAG
     const unsigned long long dg_t2 = __builtin_amdgcn_s_memtime();
 #endif
-    gemm_epilogue<8>(a, acc, m0 + wr * 128, n0 + wc * 64, fr, fq, 0);
+    // all LDS is free here: no DMA is outstanding (the last phase waited vmcnt(0)) and every wave has finished its fragment reads
+    gemm_epilogue_rows<8>(a, acc, m0 + wr * 128, n0 + wc * 64, lane, 0, lds + wave * 16384);
 #ifdef P8_DIAG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {

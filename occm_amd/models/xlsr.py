@@ -360,8 +360,8 @@ class XlsrFineTuner(XlsrFrontend):
     def __init__(self, params, cfg, device="cuda"):
         super().__init__(params, cfg, device=device, dtype=torch.bfloat16)
         D, Fd, n = cfg.dim, cfg.ffn, cfg.layers
-        if D // cfg.heads != 64:
-            raise OccError("XlsrFineTuner needs head_dim 64 (attention backward kernel)")
+        if D // cfg.heads not in (64, 80):
+            raise OccError("XlsrFineTuner needs head_dim 64 or 80 (attention backward kernel)")
         self.tshapes = []
         for i in range(n):
             self.tshapes += [("l%d.qkv.w" % i, (3 * D, D)), ("l%d.qkv.b" % i, (3 * D,)), ("l%d.o.w" % i, (D, D)), ("l%d.o.b" % i, (D,)),
@@ -484,30 +484,32 @@ class XlsrFineTuner(XlsrFrontend):
         ws = self._train_ws(B, L)
         tr = ws["tr"]
         T, M, D, Fd = ws["T"], ws["M"], cfg.dim, cfg.ffn
+        # The f32 residual stream is never copied: every layer keeps its input (x_in) and its middle state (x_mid) for backward, so
+        # out-proj reads x_in and writes x_mid, fc2 reads x_mid and writes the NEXT layer's x_in (the last one writes x_out), and the
+        # prefix writes layer 0's x_in directly.
         with torch.no_grad():
-            self._frozen_prefix(wav, ws)                         # conv stack .. positional conv -> ws["x"] (f32 residual stream)
-        x = ws["x"]
+            self._frozen_prefix(wav, ws, x_out=tr["layers"][0]["x_in"])       # conv stack .. positional conv -> f32 residual stream
         code = OCC_BF16_CODE
         xmap, hd = rowmap(M, 0, D), D // cfg.heads
         for i in range(cfg.layers):
             s = tr["layers"][i]
-            s["x_in"].copy_(x)
-            ops.layernorm(x, w["l%d.ln1.g" % i], w["l%d.ln1.b" % i], out=s["h1"])
+            x_in, x_mid = s["x_in"], s["x_mid"]
+            x_next = tr["layers"][i + 1]["x_in"] if i + 1 < cfg.layers else tr["x_out"]
+            ops.layernorm(x_in, w["l%d.ln1.g" % i], w["l%d.ln1.b" % i], out=s["h1"])
             ops.linear(s["h1"], w["l%d.qkv.w" % i], w["l%d.qkv.b" % i], out=s["qkv"])
             ops.attention(s["qkv"], B, T, cfg.heads, hd, hd ** -0.5, out=s["att"], lse=s["lse"])
-            ops.gemm_raw(M, D, D, s["att"], xmap, w["l%d.o.w" % i], D, x, xmap, OCC_F32, code, bias=w["l%d.o.b" % i], R=x, r_map=xmap, r_dtype=OCC_F32)
-            s["x_mid"].copy_(x)
-            ops.layernorm(x, w["l%d.ln2.g" % i], w["l%d.ln2.b" % i], out=s["h2"])
+            ops.gemm_raw(M, D, D, s["att"], xmap, w["l%d.o.w" % i], D, x_mid, xmap, OCC_F32, code, bias=w["l%d.o.b" % i], R=x_in, r_map=xmap, r_dtype=OCC_F32)
+            ops.layernorm(x_mid, w["l%d.ln2.g" % i], w["l%d.ln2.b" % i], out=s["h2"])
             ops.gemm_raw(M, Fd, D, s["h2"], xmap, w["l%d.fc1.w" % i], D, s["f"], rowmap(M, 0, Fd), code, code, bias=w["l%d.fc1.b" % i], act=ACT_GELU, aux=s["u"])
-            ops.gemm_raw(M, D, Fd, s["f"], rowmap(M, 0, Fd), w["l%d.fc2.w" % i], Fd, x, xmap, OCC_F32, code, bias=w["l%d.fc2.b" % i], R=x, r_map=xmap, r_dtype=OCC_F32)
-        tr["x_out"].copy_(x)
+            ops.gemm_raw(M, D, Fd, s["f"], rowmap(M, 0, Fd), w["l%d.fc2.w" % i], Fd, x_next, xmap, OCC_F32, code, bias=w["l%d.fc2.b" % i], R=x_mid, r_map=xmap, r_dtype=OCC_F32)
         out = torch.empty(B, T, D, device=self.device, dtype=torch.float32)
-        ops.layernorm(x, w["enc_ln.g"], w["enc_ln.b"], out=out.view(M, D))
+        ops.layernorm(tr["x_out"], w["enc_ln.g"], w["enc_ln.b"], out=out.view(M, D))
         self.ctx = (B, L)
         return out
 
-    def _frozen_prefix(self, wav, ws):
-        """Conv feature extractor, LayerNorm, projection, positional conv (frozen): fills ws["x"]."""
+    def _frozen_prefix(self, wav, ws, x_out=None):
+        """Conv feature extractor, LayerNorm, projection, positional conv (frozen): fills x_out (default ws["x"])."""
+        x_out = ws["x"] if x_out is None else x_out
         cfg, w, dt = self.cfg, self.w, self.dtype
         wav = wav.to(self.device, torch.float32).contiguous()
         B, L = wav.shape
@@ -533,7 +535,7 @@ class XlsrFineTuner(XlsrFrontend):
         ops.gemm_raw(M, D, 512, ws["feat"], rowmap(M, 0, 512), w["proj.w"], 512, inner, pmap, code, code, bias=w["proj.b"])
         G = cfg.pos_groups
         cg = D // G
-        ops.gemm_raw(M, cg, cfg.pos_k * cg, xpad, pmap, w["pos.w"], cfg.pos_k * cg, ws["x"], rowmap(M, 0, D), OCC_F32, code, bias=w["pos.b"], act=ACT_GELU,
+        ops.gemm_raw(M, cg, cfg.pos_k * cg, xpad, pmap, w["pos.w"], cfg.pos_k * cg, x_out, rowmap(M, 0, D), OCC_F32, code, bias=w["pos.b"], act=ACT_GELU,
                      R=inner, r_map=pmap, r_dtype=code, a_seg=(cfg.pos_k, cg, D), groups=(G, cg, cg * cfg.pos_k * cg, cg))
 
     def zero_grad(self):
@@ -719,8 +721,9 @@ class XlsrFullFineTuner(XlsrFineTuner):
             tr["conv"] = cv
         return ws
 
-    def _frozen_prefix(self, wav, ws):
+    def _frozen_prefix(self, wav, ws, x_out=None):
         """Trainable prefix in this class: same arithmetic, but every intermediate backward needs is kept."""
+        x_out = ws["x"] if x_out is None else x_out
         cfg, w = self.cfg, self.w
         cv = ws["tr"]["conv"]
         wav = wav.to(self.device, torch.float32).contiguous()
@@ -742,7 +745,7 @@ class XlsrFullFineTuner(XlsrFineTuner):
         pmap = rowmap(T, Tp * D, D)
         ops.gemm_raw(M, D, 512, cv["lnfeat"], rowmap(M, 0, 512), w["proj.w"], 512, inner, pmap, code, code, bias=w["proj.b"])
         G, cg = cfg.pos_groups, D // cfg.pos_groups
-        ops.gemm_raw(M, cg, cfg.pos_k * cg, xpad, pmap, w["pos.w"], cfg.pos_k * cg, ws["x"], rowmap(M, 0, D), OCC_F32, code, bias=w["pos.b"], act=ACT_GELU,
+        ops.gemm_raw(M, cg, cfg.pos_k * cg, xpad, pmap, w["pos.w"], cfg.pos_k * cg, x_out, rowmap(M, 0, D), OCC_F32, code, bias=w["pos.b"], act=ACT_GELU,
                      R=inner, r_map=pmap, r_dtype=code, a_seg=(cfg.pos_k, cg, D), groups=(G, cg, cg * cfg.pos_k * cg, cg), aux=cv["u_pos"])
 
     def backward(self, dfeats, grad_ready=None):

@@ -118,7 +118,8 @@ def attention_bwd(qkv, o, dout, lse, B, T, H, hd, scale, dqkv=None):
     D = H * hd
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
-    check(lib().occ_attention_bwd(ptr(qkv), ptr(o), ptr(dout), ptr(lse), ptr(dqkv), B, T, H, hd, 3 * D, D, float(scale), stream_ptr()),
+    acc = torch.empty(B * T, D, device=qkv.device, dtype=torch.float32) if T > 256 else None      # the key blocks of a head meet here
+    check(lib().occ_attention_bwd(ptr(qkv), ptr(o), ptr(dout), ptr(lse), ptr(dqkv), B, T, H, hd, 3 * D, D, float(scale), ptr(acc), stream_ptr()),
           "occ_attention_bwd")
     return dqkv
 
@@ -147,20 +148,34 @@ def transpose_bf16_rows(src, src_map, dst, rows, cols, ld_dst, colsum=None, src_
     return dst
 
 
+_SCRATCH = {}
+
+
+def small_scratch(nfloats=512 * 2048):
+    """Per (device, stream) f32 scratch for kernels that hand partial sums to a second launch (calls sharing it are ordered on that stream)."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nfloats:
+        t = _SCRATCH[key] = torch.empty(nfloats, device="cuda", dtype=torch.float32)
+    return t
+
+
 def layernorm_bwd_ex(dy, x, gamma, beta, dres, dx, dx_bf16, dx_bf16_map, dgamma, dbeta, gelu, eps=1e-5):
     """General LayerNorm backward (x f32 or bf16, optional fused GELU', f32 and/or row-mapped bf16 outputs)."""
     C = x.shape[-1]
     rows = x.numel() // C
+    sc = small_scratch()
     check(lib().occ_layernorm_bwd_ex(_p(dy), dtype_code(dy), _p(x), dtype_code(x), _p(gamma), _p(beta), _p(dres), _p(dx), _p(dx_bf16),
                                      ctypes.byref(dx_bf16_map) if dx_bf16_map is not None else None, _p(dgamma), _p(dbeta), rows, C, float(eps),
-                                     int(gelu), stream_ptr()), "occ_layernorm_bwd_ex")
+                                     int(gelu), ptr(sc), sc.numel(), stream_ptr()), "occ_layernorm_bwd_ex")
 
 
 def layernorm_bwd(dy, x, gamma, dres, dx, dgamma, dbeta, eps=1e-5, dx_bf16=None):
     C = x.shape[-1]
     rows = x.numel() // C
+    sc = small_scratch()
     check(lib().occ_layernorm_bwd(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(dgamma), ptr(dbeta), rows, C,
-                                  float(eps), stream_ptr()), "occ_layernorm_bwd")
+                                  float(eps), ptr(sc), sc.numel(), stream_ptr()), "occ_layernorm_bwd")
     return dx
 
 
