@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 L_SAMPLES = 64000
 BS_FINETUNE, BS_FROZEN = 64, 32
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-GEMM_SOURCES = ("gemm.hip", "gemm_common.h", "gemm_tn.hip", "gemm_p8.hip")
+GEMM_SOURCES = ("gemm.hip", "gemm_common.h", "gemm_tn.hip", "gemm_p8.hip", "gemm_tn_p8.hip")
 
 
 def parse_args(argv=None):
@@ -239,7 +239,7 @@ def pmc_traffic(tag):
         pm = json.load(open(path))
         if pm.get("gemm_src_sha16") != gemm_source_sha():
             return None, "profiles/%s is from other GEMM sources (%s): not reported" % (os.path.basename(path), pm.get("gemm_src_sha16"))
-        ks = [v for k, v in pm["kernels"].items() if "gemm_" in k and "bf16" in k or "gemm_p8" in k or "gemm_tn_dma" in k]
+        ks = [v for k, v in pm["kernels"].items() if ("gemm_" in k and "bf16" in k) or "gemm_tn_p8" in k or "gemm_tn_dma" in k]      # (not the slab reduce kernel)
         n = sum(v["launches"] for v in ks)
         return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks) / max(n, 1)), \
             "profiles/%s (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE, launch-weighted over the bf16 GEMM kernels)" % os.path.basename(path)

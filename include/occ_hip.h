@@ -88,10 +88,12 @@ int occ_pairwise_dist(const float* ref, const float* emb, float* dist, int64_t N
  * arrays of pointers/sizes: p -= lr * m_hat / (sqrt(v_hat) + eps).  A NULL grads[t] skips tensor t
  * (torch skips parameters whose .grad is None); steps: i32 [n] per-tensor step counters kept on the
  * device and advanced by this call (torch keeps one step per parameter).  grads are multiplied by
- * grad_scale first (1/world_size after a summing all-reduce).                                      */
+ * grad_scale first (1/world_size after a summing all-reduce).  bf16_copies (device array of n pointers,
+ * or NULL; entries may be NULL): tensor t's updated values are also written there as bf16 in the same
+ * pass (the GEMM operands of a fine-tuned front-end).                                              */
 int occ_adam_multi(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                    const int64_t* sizes, int32_t* steps, int64_t n_tensors, int64_t max_size, float lr,
-                   float beta1, float beta2, float eps, float grad_scale, void* stream);
+                   float beta1, float beta2, float eps, float grad_scale, void* const* bf16_copies, void* stream);
 
 /* ------------------------------------------------------------------ GEMM family ----------- */
 /* Row addressing shared by A, C and the residual R: with r = m % rows_per_batch, row m lives at

@@ -375,9 +375,12 @@ class XlsrFineTuner(XlsrFrontend):
             for d in shp:
                 nel *= d
             self.tslots[name] = (off, shp, nel)
-            off += (nel + 3) // 4 * 4
+            off += (nel + 7) // 8 * 8                   # 16-byte aligned slots in the bf16 mirror too (GEMM operands)
         self.P = torch.empty(off, device=self.device, dtype=torch.float32)
         self.G = torch.zeros(off, device=self.device, dtype=torch.float32)
+        # bf16 mirror of P: the forward GEMM operands are views into it; the optimizer writes it in the same pass as P (occ_adam_multi
+        # bf16_copies), so no cast kernel re-reads the f32 masters every step
+        self.Wb = torch.zeros(off, device=self.device, dtype=torch.bfloat16)
         self.mp = {k: self.P[o:o + nel].view(shp) for k, (o, shp, nel) in self.tslots.items()}
         self.mg = {k: self.G[o:o + nel].view(shp) for k, (o, shp, nel) in self.tslots.items()}
         self._load_master(params)
@@ -397,7 +400,8 @@ class XlsrFineTuner(XlsrFrontend):
             shp = self.tslots[name][1]
             if name.endswith(".w"):
                 self.wT[name] = torch.empty(shp[1], shp[0], device=self.device, dtype=torch.bfloat16)
-                self.w[name] = torch.empty(shp, device=self.device, dtype=torch.bfloat16)
+                o, _, nel = self.tslots[name]
+                self.w[name] = self.Wb[o:o + nel].view(shp)
             else:
                 self.w[name] = self.mp[name]                    # biases / LayerNorm affine are used in f32 directly
 
@@ -416,15 +420,16 @@ class XlsrFineTuner(XlsrFrontend):
             self.mp["enc_ln.g"].copy_(p["encoder.layer_norm.weight"].detach().to(self.device, torch.float32))
             self.mp["enc_ln.b"].copy_(p["encoder.layer_norm.bias"].detach().to(self.device, torch.float32))
 
-    def refresh_operands(self):
-        """bf16 W and W^T from the f32 masters (after every optimizer step)."""
+    def refresh_operands(self, cast=True):
+        """GEMM operands from the f32 masters: the bf16 mirror Wb (cast=True; after an optimizer step that wrote Wb itself, cast=False)
+        and the transposed copies W^T for the input-gradient GEMMs."""
         from .._lib import check, lib, ptr, stream_ptr
+        if cast:
+            check(lib().occ_cast(ptr(self.P), OCC_F32, ptr(self.Wb), OCC_BF16_CODE, self.P.numel(), stream_ptr()), "occ_cast")
         for name in self._encoder_names():
             shp = self.tslots[name][1]
             if name.endswith(".w"):
-                src = self.mp[name]
-                check(lib().occ_cast(ptr(src), OCC_F32, ptr(self.w[name]), dtype_code(self.w[name]), src.numel(), stream_ptr()), "occ_cast")
-                ops.transpose_bf16(src, self.wT[name], shp[0], shp[1], ld_src=shp[1], ld_dst=shp[0])
+                ops.transpose_bf16(self.mp[name], self.wT[name], shp[0], shp[1], ld_src=shp[1], ld_dst=shp[0])
 
     def export_params(self):
         """Trainable tensors back under their fairseq names (q/k/v split again)."""
@@ -639,13 +644,15 @@ class XlsrFullFineTuner(XlsrFineTuner):
             k = CONV_LAYERS[i][1]
             for n in ("b", "g", "be"):
                 self.w["c%d.%s" % (i, n)] = self.mp["c%d.%s" % (i, n)]
-            self.w["c%d.w" % i] = torch.empty(512, k * 512, device=dev, dtype=bf)
+            o, _, nel = self.tslots["c%d.w" % i]
+            self.w["c%d.w" % i] = self.Wb[o:o + nel].view(512, k * 512)          # master layout [n][tap][c] = GEMM layout [n][tap*c]
             if k == 3:
                 self.wT["c%d.we" % i] = torch.empty(512, 1024, device=dev, dtype=bf)      # [c][ (tap 2 | tap 0) x n ]
                 self.wT["c%d.wo" % i] = torch.empty(512, 512, device=dev, dtype=bf)       # tap 1
             else:
                 self.wT["c%d.wt" % i] = torch.empty(k * 512, 512, device=dev, dtype=bf)   # [(tap, c)][n]
-        self.w["proj.w"] = torch.empty(cfg.dim, 512, device=dev, dtype=bf)
+        o, _, nel = self.tslots["proj.w"]
+        self.w["proj.w"] = self.Wb[o:o + nel].view(cfg.dim, 512)
         self.wT["proj.w"] = torch.empty(512, cfg.dim, device=dev, dtype=bf)
         G, cg = cfg.pos_groups, cfg.dim // cfg.pos_groups
         self.w["pos.w"] = torch.empty(G, cg, cfg.pos_k * cg, device=dev, dtype=bf)
@@ -653,14 +660,13 @@ class XlsrFullFineTuner(XlsrFineTuner):
         self.pos_norms = torch.empty(cfg.pos_k, device=dev, dtype=torch.float32)
         self.pos_dw = torch.empty(G, cg, cfg.pos_k * cg, device=dev, dtype=torch.float32)
 
-    def refresh_operands(self):
-        super().refresh_operands()
+    def refresh_operands(self, cast=True):
+        super().refresh_operands(cast=cast)
         from .._lib import check, lib, ptr, stream_ptr
         cfg = self.cfg
         for i in range(1, 7):
             k = CONV_LAYERS[i][1]
             src = self.mp["c%d.w" % i]                       # [n][tap][c]
-            check(lib().occ_cast(ptr(src), OCC_F32, ptr(self.w["c%d.w" % i]), OCC_BF16_CODE, src.numel(), stream_ptr()), "occ_cast")
             es = 4
             if k == 3:
                 we, wo = self.wT["c%d.we" % i], self.wT["c%d.wo" % i]
@@ -671,7 +677,6 @@ class XlsrFullFineTuner(XlsrFineTuner):
             else:
                 ops.transpose_bf16(src, self.wT["c%d.wt" % i], 512, k * 512, ld_src=k * 512, ld_dst=512)
         pw = self.mp["proj.w"]
-        check(lib().occ_cast(ptr(pw), OCC_F32, ptr(self.w["proj.w"]), OCC_BF16_CODE, pw.numel(), stream_ptr()), "occ_cast")
         ops.transpose_bf16(pw, self.wT["proj.w"], cfg.dim, 512, ld_src=512, ld_dst=cfg.dim)
         G, cg = cfg.pos_groups, cfg.dim // cfg.pos_groups
         check(lib().occ_weight_norm_pack(ptr(self.mp["pos.v"]), ptr(self.mp["pos.g"]), ptr(self.w["pos.w"]), ptr(self.wT["pos.w"]), ptr(self.pos_norms),

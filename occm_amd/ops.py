@@ -278,8 +278,10 @@ def pairwise_dist(ref, emb):
 class AdamMulti:
     """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) semantics (oc_training.py:324) as one launch."""
 
-    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, bf16_copies=None):
+        """bf16_copies: optional list aligned with params (entries may be None): bf16 tensors of the same numel that receive the updated values."""
         self.params = [p for p in params]
+        self.bf16_copies = list(bf16_copies) if bf16_copies is not None else None
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         dev = self.params[0].device
@@ -290,6 +292,10 @@ class AdamMulti:
         self._v = torch.tensor([p.data_ptr() for p in self.exp_avg_sq], dtype=torch.int64, device=dev)
         self._sizes = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
         self._steps = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
+        self._b = None
+        if self.bf16_copies is not None and any(b is not None for b in self.bf16_copies):
+            assert all(b is None or (b.dtype == torch.bfloat16 and b.numel() == p.numel()) for b, p in zip(self.bf16_copies, self.params))
+            self._b = torch.tensor([0 if b is None else b.data_ptr() for b in self.bf16_copies], dtype=torch.int64, device=dev)
         self._max = max(p.numel() for p in self.params)
         self._g_host = None
         self._g = None
@@ -303,4 +309,4 @@ class AdamMulti:
         self.step_count += 1
         check(lib().occ_adam_multi(ptr(self._p), ptr(self._g), ptr(self._m), ptr(self._v), ptr(self._sizes), ptr(self._steps),
                                    len(self.params), self._max, self.lr, self.betas[0], self.betas[1], self.eps, float(grad_scale),
-                                   stream_ptr()), "occ_adam_multi")
+                                   ptr(self._b), stream_ptr()), "occ_adam_multi")

@@ -25,10 +25,10 @@ class OcTrainer:
             raise ValueError("train_frontend=True needs a model built with finetune_ssl=True")
         self.w_c, self.w_d = w_compact, w_descr
         self.group_size = group_size
-        params, self._grads = [self.be.P], [self.be.G]
-        if train_frontend:                     # transformer encoder of XLS-R is trained; the conv stack stays frozen this round
-            params.append(self.fe.P); self._grads.append(self.fe.G)
-        self.opt = ops.AdamMulti(params, lr=lr)
+        params, self._grads, mirrors = [self.be.P], [self.be.G], [None]
+        if train_frontend:                     # XLS-R is trained: its bf16 GEMM operands are written by the optimizer kernel itself
+            params.append(self.fe.P); self._grads.append(self.fe.G); mirrors.append(getattr(self.fe, "Wb", None))
+        self.opt = ops.AdamMulti(params, lr=lr, bf16_copies=mirrors)
         self.reducers = [FlatGradAllReducer(g) for g in self._grads]
         self.reducer = self.reducers[0]
         self.last = None
@@ -119,6 +119,6 @@ class OcTrainer:
         for r in self.reducers:
             r.all_reduce()
         self.opt.step(self._grads, grad_scale=self.reducer.grad_scale)
-        fe.refresh_operands()
+        fe.refresh_operands(cast=not hasattr(fe, "Wb"))
         self.last = (lc, ld)
         return lc, ld

@@ -24,5 +24,13 @@ for k in sorted(set(ft) | set(wt)):
     f = ft[k] / max(fc[k], 1); w = wt[k] / max(wc[k], 1)
     out["kernels"][k] = {"FETCH_SIZE_KiB_per_launch": round(f, 1), "WRITE_SIZE_KiB_per_launch": round(w, 1),
                          "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024), "launches": max(fc[k], wc[k])}
+import hashlib, os
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _n in ("gemm.hip", "gemm_common.h", "gemm_tn.hip", "gemm_p8.hip", "gemm_tn_p8.hip"):       # the same list as bench.py GEMM_SOURCES: the profile is tied to these sources
+    _p = os.path.join(_root, "occm_amd", "csrc", _n)
+    if os.path.exists(_p):
+        _h.update(open(_p, "rb").read())
+out["gemm_src_sha16"] = _h.hexdigest()[:16]
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print("wrote", sys.argv[3], len(out["kernels"]), "kernels")

@@ -53,7 +53,9 @@ def test_adam_multi_matches_torch_adam():
     ref = [p.clone().requires_grad_(True) for p in ps]
     opt = torch.optim.Adam(ref, lr=1e-3)
     dev = [p.clone().cuda() for p in ps]
-    mine = ops.AdamMulti(dev, lr=1e-3)
+    # tensors 0 and 3 also get a bf16 mirror written by the same launch (the GEMM operands of a fine-tuned front-end); 4 is odd-sized
+    mirrors = [torch.zeros(p.numel(), device="cuda", dtype=torch.bfloat16) if i in (0, 3, 4) else None for i, p in enumerate(ps)]
+    mine = ops.AdamMulti(dev, lr=1e-3, bf16_copies=mirrors)
     for step in range(5):
         grads = [torch.randn(s, generator=g) for s in shapes]
         grads_dev = [x.cuda() for x in grads]
@@ -65,3 +67,6 @@ def test_adam_multi_matches_torch_adam():
         mine.step(grads_dev)
     for p, q in zip(ref, dev):
         torch.testing.assert_close(q.cpu(), p.detach(), rtol=2e-5, atol=2e-6)
+    for q, m in zip(dev, mirrors):
+        if m is not None:
+            assert torch.equal(m.view(q.shape), q.bfloat16())
