@@ -310,6 +310,11 @@ int occ_transpose_bf16_rows(const void* src, int src_dtype, const occ_rowmap* sr
 int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
                          const float* dres, float* dx, void* dx_bf16, const occ_rowmap* dx_bf16_map, float* dgamma, float* dbeta,
                          int64_t rows, int64_t C, float eps, int gelu, float* scratch, int64_t scratch_floats, void* stream);
+/* y = residual + scale * x * keep / (1 - p), x / y f32 or bf16 (may alias), residual f32 or NULL, mask u8 [n] or NULL (= no dropout):
+ * the train-mode dropouts of fairseq's Wav2Vec2Model (dropout_input, dropout, activation_dropout; active because the reference calls
+ * aasist.train(), oc_training.py:351) and their backward (generate = 0 with the stored mask).  generate != 0 draws the mask (Philox).   */
+int occ_dropout_ex(const void* x, int x_dtype, void* y, int y_dtype, uint8_t* mask, const float* residual, int64_t n, float p, float scale,
+                   uint64_t seed, uint64_t stream_id, int generate, void* stream);
 /* out (bf16, through out_map) = dy (f32 [rows,C]) * gelu'(u (bf16 [rows,C])): gradient through the positional conv's GELU.   */
 int occ_gelu_bwd_rows(const float* dy, const void* u, void* out, const occ_rowmap* out_map, int64_t rows, int64_t C, void* stream);
 /* Backward of occ_conv0_ln_gelu (recomputes the block from the waveform): dw [C,k], dbias, dgamma, dbeta accumulated.       */

@@ -329,6 +329,40 @@ __global__ __launch_bounds__(256) void layernorm_bwd_finalize_kernel(const float
     }
 }
 
+// y = residual + scale * x * keep / (1 - p): fairseq's train-mode dropouts inside wav2vec2 (dropout_input, the encoder's and the
+// layers' dropout / activation_dropout) and their backward (the same call with the stored mask on the gradient).  mask NULL = no
+// dropout (plain scale / add); gen != 0 draws the keep-mask (Philox 4x32-10, one counter per 4 elements, as occ_dropout) and stores it.
+__device__ __forceinline__ void fb_philox_r(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+template <typename TX, typename TY>
+__global__ void dropout_ex_kernel(const TX* __restrict__ x, TY* __restrict__ y, unsigned char* __restrict__ mask, const float* __restrict__ residual,
+                                  long long n, float p, float scale, uint64_t seed, uint64_t sid, int gen) {
+    const float sc = scale / (1.0f - p);
+    const long long nq = (n + 3) / 4;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
+        if (gen && mask) {
+            uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+            for (int r = 0; r < 10; ++r) { fb_philox_r(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const long long i = q * 4 + h;
+            if (i < n) {
+                unsigned char m = 1;
+                if (mask) { if (gen) { m = ((float)c[h] * (1.0f / 4294967296.0f)) >= p ? 1 : 0; mask[i] = m; } else m = mask[i]; }
+                float v = m ? occ_load_f32(x + i) * sc : 0.f;
+                if (residual) v += residual[i];
+                occ_store_f32(y + i, v);
+            }
+        }
+    }
+}
+
 // out[omap(r)][c] = bf16(dy[r][c] * gelu'(u[r][c]))   (gradient through the positional conv's GELU, written into the padded buffer)
 __global__ void gelu_bwd_rows_kernel(const float* __restrict__ dy, const unsigned short* __restrict__ u, unsigned short* __restrict__ out, RowMapI omap,
                                      long long rows, int C) {
@@ -559,6 +593,24 @@ int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
 int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
                       float* dbeta, int64_t rows, int64_t C, float eps, float* scratch, int64_t scratch_floats, void* stream) {
     return occ_layernorm_bwd_ex(dy, dy_dtype, x, OCC_F32, gamma, nullptr, dres, dx, dx_bf16, nullptr, dgamma, dbeta, rows, C, eps, 0, scratch, scratch_floats, stream);
+}
+
+int occ_dropout_ex(const void* x, int x_dtype, void* y, int y_dtype, uint8_t* mask, const float* residual, int64_t n, float p, float scale, uint64_t seed,
+                   uint64_t stream_id, int generate, void* stream) {
+    OCC_CHECK_ARG(x && y && n >= 0 && p >= 0.f && p < 1.f, "occ_dropout_ex: bad argument");
+    OCC_CHECK_ARG((x_dtype == OCC_F32 || x_dtype == OCC_BF16) && (y_dtype == OCC_F32 || y_dtype == OCC_BF16), "occ_dropout_ex: dtypes must be f32 or bf16");
+    if (n == 0) return OCC_OK;
+    long long blocks = occ_cdiv(occ_cdiv(n, 4), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = (hipStream_t)stream;
+#define OCC_DX(TX, TY) hipLaunchKernelGGL((dropout_ex_kernel<TX, TY>), dim3((unsigned)blocks), dim3(256), 0, s, (const TX*)x, (TY*)y, mask, residual, (long long)n, p, scale, seed, stream_id, generate)
+    if (x_dtype == OCC_F32 && y_dtype == OCC_F32) OCC_DX(float, float);
+    else if (x_dtype == OCC_F32) OCC_DX(float, unsigned short);
+    else if (y_dtype == OCC_F32) OCC_DX(unsigned short, float);
+    else OCC_DX(unsigned short, unsigned short);
+#undef OCC_DX
+    OCC_LAUNCH_CHECK("occ_dropout_ex");
+    return OCC_OK;
 }
 
 int occ_gelu_bwd_rows(const float* dy, const void* u, void* out, const occ_rowmap* out_map, int64_t rows, int64_t C, void* stream) {

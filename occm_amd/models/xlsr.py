@@ -388,6 +388,13 @@ class XlsrFineTuner(XlsrFrontend):
         self._alloc_operands()
         self.refresh_operands()
         self.ctx = None
+        # fairseq train-mode behaviour (XlsrTrainCfg; all zero by default): keep-masks are drawn with Philox (drop_seed, step, site) and
+        # kept for backward; tests inject them through ``inject_masks`` / ``inject_keep`` to drive the oracle with the same masks
+        self.train_cfg = XlsrTrainCfg()
+        self.dropout_active = True
+        self.drop_seed, self.drop_step = 0, 0
+        self.inject_masks, self.inject_keep = None, None
+        self.masks, self.keep = {}, None
 
     def _extra_shapes(self):
         return []
@@ -482,6 +489,31 @@ class XlsrFineTuner(XlsrFrontend):
             ws["tr"] = tr
         return ws
 
+    # ---- train-mode dropouts ---------------------------------------------------------------------------------------------
+    def _p(self, field):
+        return getattr(self.train_cfg, field) if self.dropout_active else 0.0
+
+    def _mask(self, site, like):
+        """Keep-mask (u8, like.numel()) of a dropout site: injected by a test, or a fresh buffer that occ_dropout_ex fills (generate=1)."""
+        if self.inject_masks is not None:
+            m = self.inject_masks[site].to(self.device, torch.uint8).contiguous().view(-1)
+            self.masks[site] = m
+            return m, False
+        m = self.masks.get(site)
+        if m is None or m.numel() != like.numel():
+            m = self.masks[site] = torch.empty(like.numel(), device=self.device, dtype=torch.uint8)
+        return m, True
+
+    def _drop_fwd(self, site, x, y, p, residual=None):
+        """y = residual + dropout_p(x) at `site` (train mode)."""
+        m, gen = self._mask(site, x)
+        import zlib
+        sid = (self.drop_step << 12) + (zlib.crc32(site.encode()) & 0xfff)
+        ops.dropout_ex(x, y, m, p, seed=self.drop_seed, stream_id=sid, generate=gen, residual=residual)
+
+    def _drop_bwd(self, site, dy, dx, p):
+        ops.dropout_ex(dy, dx, self.masks[site], p, generate=False)
+
     def forward_train(self, wav):
         """wav f32 [B,L] -> features f32 [B,T,dim]; keeps the tape for backward()."""
         cfg, w = self.cfg, self.w
@@ -489,6 +521,20 @@ class XlsrFineTuner(XlsrFrontend):
         ws = self._train_ws(B, L)
         tr = ws["tr"]
         T, M, D, Fd = ws["T"], ws["M"], cfg.dim, cfg.ffn
+        if self.train_cfg.attention_dropout > 0 and self.dropout_active:
+            raise OccError("attention_dropout > 0 is not implemented (the published XLS-R configurations use 0)")
+        p_res, p_act, p_ld = self._p("dropout"), self._p("activation_dropout"), self._p("encoder_layerdrop")
+        self.drop_step += 1
+        if self.inject_keep is not None:
+            self.keep = [bool(k) for k in self.inject_keep]
+        elif p_ld > 0:                                           # fairseq: np.random.random() > layerdrop keeps the layer
+            import numpy as np
+            self.keep = [bool(np.random.random() > p_ld) for _ in range(cfg.layers)]
+        else:
+            self.keep = [True] * cfg.layers
+        if (p_res > 0 or p_act > 0) and "y" not in tr:
+            tr["y"] = torch.empty(M, D, device=self.device, dtype=torch.float32)       # branch output before its dropout
+            tr["dyb"] = torch.empty(M, D, device=self.device, dtype=torch.bfloat16)    # dropped gradient of a branch output
         # The f32 residual stream is never copied: every layer keeps its input (x_in) and its middle state (x_mid) for backward, so
         # out-proj reads x_in and writes x_mid, fc2 reads x_mid and writes the NEXT layer's x_in (the last one writes x_out), and the
         # prefix writes layer 0's x_in directly.
@@ -496,17 +542,33 @@ class XlsrFineTuner(XlsrFrontend):
             self._frozen_prefix(wav, ws, x_out=tr["layers"][0]["x_in"])       # conv stack .. positional conv -> f32 residual stream
         code = OCC_BF16_CODE
         xmap, hd = rowmap(M, 0, D), D // cfg.heads
+        if p_res > 0:                                            # TransformerEncoder.extract_features: x = F.dropout(x + pos_conv(x), p=dropout)
+            x0 = tr["layers"][0]["x_in"]
+            self._drop_fwd("enc", x0, x0, p_res)
         for i in range(cfg.layers):
             s = tr["layers"][i]
             x_in, x_mid = s["x_in"], s["x_mid"]
             x_next = tr["layers"][i + 1]["x_in"] if i + 1 < cfg.layers else tr["x_out"]
+            if not self.keep[i]:                                 # layerdrop: the layer is skipped, the residual stream passes through
+                x_next.copy_(x_in)
+                continue
             ops.layernorm(x_in, w["l%d.ln1.g" % i], w["l%d.ln1.b" % i], out=s["h1"])
             ops.linear(s["h1"], w["l%d.qkv.w" % i], w["l%d.qkv.b" % i], out=s["qkv"])
             ops.attention(s["qkv"], B, T, cfg.heads, hd, hd ** -0.5, out=s["att"], lse=s["lse"])
-            ops.gemm_raw(M, D, D, s["att"], xmap, w["l%d.o.w" % i], D, x_mid, xmap, OCC_F32, code, bias=w["l%d.o.b" % i], R=x_in, r_map=xmap, r_dtype=OCC_F32)
+            if p_res > 0:                                        # x = residual + dropout1(self_attn(LN(x)))
+                ops.gemm_raw(M, D, D, s["att"], xmap, w["l%d.o.w" % i], D, tr["y"], xmap, OCC_F32, code, bias=w["l%d.o.b" % i])
+                self._drop_fwd("l%d.d1" % i, tr["y"], x_mid, p_res, residual=x_in)
+            else:
+                ops.gemm_raw(M, D, D, s["att"], xmap, w["l%d.o.w" % i], D, x_mid, xmap, OCC_F32, code, bias=w["l%d.o.b" % i], R=x_in, r_map=xmap, r_dtype=OCC_F32)
             ops.layernorm(x_mid, w["l%d.ln2.g" % i], w["l%d.ln2.b" % i], out=s["h2"])
             ops.gemm_raw(M, Fd, D, s["h2"], xmap, w["l%d.fc1.w" % i], D, s["f"], rowmap(M, 0, Fd), code, code, bias=w["l%d.fc1.b" % i], act=ACT_GELU, aux=s["u"])
-            ops.gemm_raw(M, D, Fd, s["f"], rowmap(M, 0, Fd), w["l%d.fc2.w" % i], Fd, x_next, xmap, OCC_F32, code, bias=w["l%d.fc2.b" % i], R=x_mid, r_map=xmap, r_dtype=OCC_F32)
+            if p_act > 0:                                        # dropout2 on the activation
+                self._drop_fwd("l%d.act" % i, s["f"], s["f"], p_act)
+            if p_res > 0:                                        # x = residual + dropout3(fc2(.))
+                ops.gemm_raw(M, D, Fd, s["f"], rowmap(M, 0, Fd), w["l%d.fc2.w" % i], Fd, tr["y"], xmap, OCC_F32, code, bias=w["l%d.fc2.b" % i])
+                self._drop_fwd("l%d.d3" % i, tr["y"], x_next, p_res, residual=x_mid)
+            else:
+                ops.gemm_raw(M, D, Fd, s["f"], rowmap(M, 0, Fd), w["l%d.fc2.w" % i], Fd, x_next, xmap, OCC_F32, code, bias=w["l%d.fc2.b" % i], R=x_mid, r_map=xmap, r_dtype=OCC_F32)
         out = torch.empty(B, T, D, device=self.device, dtype=torch.float32)
         ops.layernorm(tr["x_out"], w["enc_ln.g"], w["enc_ln.b"], out=out.view(M, D))
         self.ctx = (B, L)
@@ -575,23 +637,39 @@ class XlsrFineTuner(XlsrFrontend):
         xmap, fmap, qmap = rowmap(M, 0, D), rowmap(M, 0, Fd), rowmap(M, 0, 3 * D)
         dx, dxb = tr["dx"], tr["dxb"]
         ops.layernorm_bwd(dfeats.contiguous().view(M, D), tr["x_out"], w["enc_ln.g"], None, dx, self.mg["enc_ln.g"], self.mg["enc_ln.b"], dx_bf16=dxb)
+        p_res, p_act = self._p("dropout"), self._p("activation_dropout")
         for i in range(cfg.layers - 1, -1, -1):
             s = tr["layers"][i]
-            # ---- FFN: x3 = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-            self._wgrad(dxb, s["f"], D, Fd, M, "l%d.fc2.w" % i, "l%d.fc2.b" % i)
-            ops.gemm_raw(M, Fd, D, dxb, xmap, self.wT["l%d.fc2.w" % i], D, tr["du"], fmap, bfc, bfc, act=ACT_GELU_GRAD, aux=s["u"])
+            if not self.keep[i]:                                 # a dropped layer: the gradient passes through, its parameters get none
+                if grad_ready is not None:
+                    grad_ready(*self.layer_grad_range(i))
+                continue
+            # ---- FFN: x3 = x_mid + dropout3(fc2(dropout2(gelu(fc1(LN2(x_mid))))))
+            dyb = dxb
+            if p_res > 0:
+                dyb = tr["dyb"]; self._drop_bwd("l%d.d3" % i, dxb, dyb, p_res)
+            self._wgrad(dyb, s["f"], D, Fd, M, "l%d.fc2.w" % i, "l%d.fc2.b" % i)
+            ops.gemm_raw(M, Fd, D, dyb, xmap, self.wT["l%d.fc2.w" % i], D, tr["du"], fmap, bfc, bfc, act=ACT_GELU_GRAD, aux=s["u"])
+            if p_act > 0:                                        # (elementwise factors commute: mask after GELU')
+                self._drop_bwd("l%d.act" % i, tr["du"], tr["du"], p_act)
             self._wgrad(tr["du"], s["h2"], Fd, D, M, "l%d.fc1.w" % i, "l%d.fc1.b" % i)
             ops.gemm_raw(M, D, Fd, tr["du"], fmap, self.wT["l%d.fc1.w" % i], Fd, tr["dh"], xmap, bfc, bfc)
             ops.layernorm_bwd(tr["dh"], s["x_mid"], w["l%d.ln2.g" % i], dx, dx, self.mg["l%d.ln2.g" % i], self.mg["l%d.ln2.b" % i], dx_bf16=dxb)
-            # ---- attention: x_mid = x_in + out_proj(attn(qkv(LN1(x_in))))
-            self._wgrad(dxb, s["att"], D, D, M, "l%d.o.w" % i, "l%d.o.b" % i)
-            ops.gemm_raw(M, D, D, dxb, xmap, self.wT["l%d.o.w" % i], D, tr["da"], xmap, bfc, bfc)
+            # ---- attention: x_mid = x_in + dropout1(out_proj(attn(qkv(LN1(x_in)))))
+            dyb = dxb
+            if p_res > 0:
+                dyb = tr["dyb"]; self._drop_bwd("l%d.d1" % i, dxb, dyb, p_res)
+            self._wgrad(dyb, s["att"], D, D, M, "l%d.o.w" % i, "l%d.o.b" % i)
+            ops.gemm_raw(M, D, D, dyb, xmap, self.wT["l%d.o.w" % i], D, tr["da"], xmap, bfc, bfc)
             ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
             self._wgrad(tr["dqkv"], s["h1"], 3 * D, D, M, "l%d.qkv.w" % i, "l%d.qkv.b" % i)
             ops.gemm_raw(M, D, 3 * D, tr["dqkv"], qmap, self.wT["l%d.qkv.w" % i], 3 * D, tr["dh"], xmap, bfc, bfc)
             ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i], dx_bf16=dxb)
             if grad_ready is not None:
                 grad_ready(*self.layer_grad_range(i))
+        if p_res > 0:                                            # the encoder's input dropout
+            self._drop_bwd("enc", dx, dx, p_res)
+            self._drop_bwd("enc", dxb, dxb, p_res)
         self.ctx = None
 
 
@@ -748,7 +826,14 @@ class XlsrFullFineTuner(XlsrFineTuner):
         Tp, half = T + cfg.pos_k, cfg.pos_k // 2
         inner = xpad.data_ptr() + half * D * xpad.element_size()
         pmap = rowmap(T, Tp * D, D)
-        ops.gemm_raw(M, D, 512, cv["lnfeat"], rowmap(M, 0, 512), w["proj.w"], 512, inner, pmap, code, code, bias=w["proj.b"])
+        p_in = self._p("dropout_input")
+        if p_in > 0:                                             # Wav2Vec2Model.forward: features = dropout_input(post_extract_proj(features))
+            tmp = cv.setdefault("proj_tmp", torch.empty(M, D, device=self.device, dtype=torch.bfloat16))
+            ops.gemm_raw(M, D, 512, cv["lnfeat"], rowmap(M, 0, 512), w["proj.w"], 512, tmp, rowmap(M, 0, D), code, code, bias=w["proj.b"])
+            self._drop_fwd("in", tmp, tmp, p_in)
+            xpad.view(B, Tp, D)[:, half:half + T].copy_(tmp.view(B, T, D))
+        else:
+            ops.gemm_raw(M, D, 512, cv["lnfeat"], rowmap(M, 0, 512), w["proj.w"], 512, inner, pmap, code, code, bias=w["proj.b"])
         G, cg = cfg.pos_groups, D // cfg.pos_groups
         ops.gemm_raw(M, cg, cfg.pos_k * cg, xpad, pmap, w["pos.w"], cfg.pos_k * cg, x_out, rowmap(M, 0, D), OCC_F32, code, bias=w["pos.b"], act=ACT_GELU,
                      R=inner, r_map=pmap, r_dtype=code, a_seg=(cfg.pos_k, cg, D), groups=(G, cg, cg * cfg.pos_k * cg, cg), aux=cv["u_pos"])
@@ -782,10 +867,18 @@ class XlsrFullFineTuner(XlsrFineTuner):
         ops.gemm_raw(M, cg, Kp * cg, dupad, dmap, self.wT["pos.w"], Kp * cg, dx, xm, OCC_F32, bfc, R=dx, r_map=xm, r_dtype=OCC_F32,
                      a_seg=(Kp, cg, D), groups=(G, cg, cg * Kp * cg, cg))
         # ---- post_extract_proj + LayerNorm(512) --------------------------------------------------------------------
+        if self._p("dropout_input") > 0:
+            self._drop_bwd("in", dx, dx, self._p("dropout_input"))
         check(lib().occ_cast(ptr(dx), OCC_F32, ptr(tr["dxb"]), bfc, M * D, stream_ptr()), "occ_cast")      # dx changed since its bf16 copy was made
         self._wgrad(tr["dxb"], cv["lnfeat"], D, 512, M, "proj.w", "proj.b")
         ops.gemm_raw(M, 512, D, dx, xm, self.wT["proj.w"], D, cv["dln"], rowmap(M, 0, 512), bfc, OCC_AF32_WBF16)
         ops.layernorm_bwd_ex(cv["dln"], cv["act"][6].view(M, 512), w["ln.g"], None, None, None, cv["dact"][6].view(M, 512), None, self.mg["ln.g"], self.mg["ln.b"], gelu=False)
+        # fairseq scales the gradient that enters the conv feature extractor (GradMultiply, feature_grad_mult; 0 = extractor not trained)
+        fgm = self.train_cfg.feature_grad_mult
+        if fgm == 0.0:
+            return
+        if fgm != 1.0:
+            ops.dropout_ex(cv["dact"][6], cv["dact"][6], None, 0.0, scale=fgm)
         # ---- conv blocks 6..1 ------------------------------------------------------------------------------------------
         for i in range(6, 0, -1):
             _, k, s = CONV_LAYERS[i]

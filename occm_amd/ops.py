@@ -148,6 +148,13 @@ def transpose_bf16_rows(src, src_map, dst, rows, cols, ld_dst, colsum=None, src_
     return dst
 
 
+def dropout_ex(x, y, mask, p, seed=0, stream_id=0, generate=False, residual=None, scale=1.0):
+    """y = residual + scale * x * keep / (1 - p) (x, y f32 or bf16, may alias; mask u8 or None)."""
+    check(lib().occ_dropout_ex(ptr(x), dtype_code(x), ptr(y), dtype_code(y), ptr(mask), ptr(residual), x.numel(), float(p), float(scale), int(seed),
+                               int(stream_id), int(generate), stream_ptr()), "occ_dropout_ex")
+    return y
+
+
 _SCRATCH = {}
 
 

@@ -87,8 +87,17 @@ def conv_features(wav, p, upto=None):
     return x.transpose(1, 2)                                       # [B,T,512]
 
 
-def encoder_layer(x, p, pre, heads):
-    """TransformerSentenceEncoderLayer with layer_norm_first=True (pre-LN), no dropout."""
+def _drop(x, masks, site, p):
+    """F.dropout with an explicit keep-mask (u8, x's shape): x * keep / (1 - p); site absent or p == 0 = identity."""
+    if masks is None or p <= 0 or site not in masks:
+        return x
+    return x * masks[site].to(x.dtype).reshape(x.shape) / (1.0 - p)
+
+
+def encoder_layer(x, p, pre, heads, masks=None, site=None, p_res=0.0, p_act=0.0):
+    """TransformerSentenceEncoderLayer with layer_norm_first=True (pre-LN).  Train mode (masks given): dropout1 on the attention
+    branch, dropout2 (activation_dropout) after the activation, dropout3 on the FFN branch -- fairseq wav2vec2.py
+    TransformerSentenceEncoderLayer.forward."""
     B, T, D = x.shape
     hd = D // heads
     h = F.layer_norm(x, (D,), p[pre + ".self_attn_layer_norm.weight"], p[pre + ".self_attn_layer_norm.bias"])
@@ -100,19 +109,34 @@ def encoder_layer(x, p, pre, heads):
     v = v.view(B, T, heads, hd).transpose(1, 2)
     a = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v         # [B,H,T,hd]
     a = a.transpose(1, 2).reshape(B, T, D)
-    x = x + F.linear(a, p[pre + ".self_attn.out_proj.weight"], p[pre + ".self_attn.out_proj.bias"])
+    y = F.linear(a, p[pre + ".self_attn.out_proj.weight"], p[pre + ".self_attn.out_proj.bias"])
+    x = x + _drop(y, masks, "%s.d1" % site, p_res)
     h = F.layer_norm(x, (D,), p[pre + ".final_layer_norm.weight"], p[pre + ".final_layer_norm.bias"])
-    h = F.gelu(F.linear(h, p[pre + ".fc1.weight"], p[pre + ".fc1.bias"]))
-    return x + F.linear(h, p[pre + ".fc2.weight"], p[pre + ".fc2.bias"])
+    h = _drop(F.gelu(F.linear(h, p[pre + ".fc1.weight"], p[pre + ".fc1.bias"])), masks, "%s.act" % site, p_act)
+    return x + _drop(F.linear(h, p[pre + ".fc2.weight"], p[pre + ".fc2.bias"]), masks, "%s.d3" % site, p_res)
 
 
-def extract_feat(wav, p, cfg, taps=None):
-    """wav [B,L] (un-normalised, as the reference feeds it) -> [B,T,dim]."""
+def extract_feat(wav, p, cfg, taps=None, train=None):
+    """wav [B,L] (un-normalised, as the reference feeds it) -> [B,T,dim].
+
+    train (optional): fairseq's train-mode behaviour, active in the reference because ``aasist.train()`` (oc_training.py:351) also
+    puts the never-eval()-ed SSLModel (sslassist.py:20-29) in train mode.  A dict with the probabilities ``dropout``,
+    ``activation_dropout``, ``dropout_input``, ``feature_grad_mult``, the explicit keep-masks ``masks`` {site: u8} (sites "in",
+    "enc", "l<i>.d1", "l<i>.act", "l<i>.d3") and the layerdrop decisions ``keep`` [bool per layer] -- Wav2Vec2Model.forward and
+    TransformerEncoder.extract_features of fairseq @ a540213."""
+    tr = train or {}
+    masks, keep = tr.get("masks"), tr.get("keep")
     f = conv_features(wav, p)
     if taps is not None:
         taps["conv"] = f
+    fgm = tr.get("feature_grad_mult", 1.0)
+    if fgm == 0.0:                                                 # fairseq runs the extractor under no_grad
+        f = f.detach()
+    elif fgm != 1.0:                                               # GradMultiply.apply(features, fgm): identity forward, gradient x fgm
+        f = f.detach() * (1.0 - fgm) + f * fgm
     f = F.layer_norm(f, (cfg.conv_dim,), p["layer_norm.weight"], p["layer_norm.bias"])
     x = F.linear(f, p["post_extract_proj.weight"], p["post_extract_proj.bias"])
+    x = _drop(x, masks, "in", tr.get("dropout_input", 0.0))
     if taps is not None:
         taps["proj"] = x
     pc = F.conv1d(x.transpose(1, 2), pos_conv_weight(p), p["encoder.pos_conv.0.bias"],
@@ -120,10 +144,12 @@ def extract_feat(wav, p, cfg, taps=None):
     if cfg.pos_k % 2 == 0:
         pc = pc[:, :, :-1]                                         # SamePad
     x = x + F.gelu(pc).transpose(1, 2)
+    x = _drop(x, masks, "enc", tr.get("dropout", 0.0))
     if taps is not None:
         taps["pos"] = x
     for i in range(cfg.layers):
-        x = encoder_layer(x, p, "encoder.layers.%d" % i, cfg.heads)
+        if keep is None or keep[i]:
+            x = encoder_layer(x, p, "encoder.layers.%d" % i, cfg.heads, masks, "l%d" % i, tr.get("dropout", 0.0), tr.get("activation_dropout", 0.0))
         if taps is not None:
             taps["layer%d" % i] = x
     return F.layer_norm(x, (cfg.dim,), p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"])

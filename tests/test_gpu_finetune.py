@@ -239,3 +239,64 @@ def test_backward_reports_layer_gradient_ranges_for_overlapped_allreduce():
     assert all(lo1 <= ft.tslots[n][0] and ft.tslots[n][0] + ft.tslots[n][2] <= hi1 for n in names) and len(names) == 12
     for (lo, hi), snap in zip(seen, snaps):
         assert torch.equal(snap, ft.G[lo:hi]) and float(snap.abs().max()) > 0
+
+
+def test_finetuner_train_mode_dropouts_layerdrop_and_feature_grad_mult_match_oracle():
+    """fairseq's train-mode behaviour of Wav2Vec2Model (active in the reference: aasist.train(), oc_training.py:351, on an SSLModel that
+    is never eval()-ed): dropout_input on the projection, the encoder's input dropout, dropout1/2/3 of every layer, layerdrop and
+    feature_grad_mult.  The keep-masks the HIP path draws (Philox) are read back and drive the oracle; outputs and every gradient must
+    then agree as in eval mode."""
+    from oracle import xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.models import xlsr
+    kw = dict(dim=256, ffn=512, heads=4, layers=3)
+    rcfg, cfg = xlsr_ref.XlsrConfig(**kw), xlsr.XlsrConfig(**kw)
+    p = fill_like(xlsr_ref.param_shapes(rcfg), seed=3)
+    for v in p.values():
+        v.requires_grad_(True)
+    L = 8000
+    wav = 0.1 * _r(2, L, seed=5)
+    ft = xlsr.XlsrFullFineTuner({k: v.detach() for k, v in p.items()}, cfg)
+    ft.train_cfg = xlsr.XlsrTrainCfg(dropout=0.1, activation_dropout=0.2, dropout_input=0.15, encoder_layerdrop=0.3, feature_grad_mult=0.25)
+    ft.inject_keep = [True, False, True]                      # the layerdrop draw is the host's (np.random in fairseq): fixed here
+    ft.drop_seed = 7
+    out = ft.forward_train(wav.cuda())
+    T, D, Fd = xlsr_ref.n_frames(L), 256, 512
+    masks = {k: v.cpu() for k, v in ft.masks.items()}
+    assert set(masks) == {"in", "enc", "l0.d1", "l0.act", "l0.d3", "l2.d1", "l2.act", "l2.d3"}         # no masks for the dropped layer
+    for site, pr in (("in", 0.15), ("enc", 0.1), ("l0.act", 0.2), ("l2.d3", 0.1)):
+        assert abs(1.0 - float(masks[site].float().mean()) - pr) < 0.02, site                         # drop rates
+    shapes = {"in": (2, T, D), "enc": (2, T, D)}
+    om = {k: v.view(shapes.get(k, (2, T, Fd if k.endswith("act") else D))) for k, v in masks.items()}
+    train = dict(dropout=0.1, activation_dropout=0.2, dropout_input=0.15, feature_grad_mult=0.25, masks=om, keep=[True, False, True])
+    ref = xlsr_ref.extract_feat(wav, p, rcfg, train=train)
+    err = (out.cpu() - ref.detach()).abs()
+    assert float(err.max()) < 8e-2 and float(err.mean()) < 1.2e-2, (float(err.max()), float(err.mean()))
+    dfe = _r(*ref.shape, seed=6)
+    (ref * dfe).sum().backward()
+    ft.zero_grad()
+    ft.backward(dfe.cuda())
+    grads = ft.grad_dict()
+    gmax = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
+    bad = []
+    for k, v in p.items():
+        g = grads[k].cpu().reshape(-1)
+        if v.grad is None or float(v.grad.abs().max()) < 1e-5 * gmax:
+            assert float(g.abs().max()) < 2e-2 * gmax, (k, float(g.abs().max()), gmax)               # dropped layer: no gradient at all
+            continue
+        r = v.grad.reshape(-1)
+        cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-30))
+        rel = float((g - r).abs().max() / (r.abs().max() + 1e-30))
+        if cos < 0.99 or rel > 8e-2:
+            bad.append((k, round(cos, 5), round(rel, 4)))
+    assert not bad, bad[:12]
+    assert float(grads["encoder.layers.1.fc1.weight"].abs().max()) == 0.0
+    # a second step draws other masks; attention_dropout is refused
+    m0 = ft.masks["enc"].clone()
+    ft.inject_keep = None
+    ft.forward_train(wav.cuda())
+    assert not torch.equal(m0, ft.masks["enc"])
+    ft.train_cfg.attention_dropout = 0.1
+    from occm_amd._lib import OccError
+    with pytest.raises(OccError):
+        ft.forward_train(wav.cuda())

@@ -96,7 +96,9 @@ def test_oc_training_entry_point_runs_and_saves_checkpoint(tmp_path, monkeypatch
     d.mkdir(); v.mkdir()
     lines = []
     for i in range(7):
-        lines.append(f"LA_00{i} B{i} - - bonafide"); _write_wav(str(d / f"B{i}.wav"), 16000 + 300 * i, i)
+        # one utterance of 5.7 s: PFDataset zero-pads the group to it (oc_training.py:244-249), i.e. 284 frames -- longer than one key
+        # block of the attention backward, which the reference's variable-length groups need when XLS-R is fine-tuned
+        lines.append(f"LA_00{i} B{i} - - bonafide"); _write_wav(str(d / f"B{i}.wav"), 91000 if i == 2 else 16000 + 300 * i, i)
         for k, name in enumerate(VOCODERS):
             _write_wav(str(v / f"{name}_B{i}.wav"), 16000 + 50 * k, 100 + i * 5 + k)
     for i in range(3):
