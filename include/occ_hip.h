@@ -23,7 +23,9 @@ extern "C" {
 
 enum occ_status { OCC_OK = 0, OCC_EINVAL = -1, OCC_ELAUNCH = -2, OCC_EUNSUPPORTED = -3 };
 enum occ_dtype { OCC_F32 = 0, OCC_BF16 = 1, OCC_F64 = 2, OCC_F32_AS_BF16 = 3 /* occ_gemm ab_dtype only: f32 operands in memory, rounded to bf16 on the way into LDS, bf16 MFMA */,
-                 OCC_AF32_WBF16 = 4 /* occ_gemm ab_dtype only: A f32 in memory (rounded to bf16 while staged), W bf16 */ };
+                 OCC_AF32_WBF16 = 4 /* occ_gemm ab_dtype only: A f32 in memory (rounded to bf16 while staged), W bf16 */,
+                 OCC_FP8_E4M3 = 5, OCC_FP8_E5M2 = 6 /* OCP 8-bit floats (e4m3fn / e5m2), one byte per element: occ_fp8_quantize output;
+                    as occ_gemm ab_dtype: A in that format, W e4m3, products on v_mfma_scale_f32_16x16x128_f8f6f4, f32 accumulate */ };
 enum occ_act { OCC_ACT_NONE = 0, OCC_ACT_GELU = 1, OCC_ACT_SELU = 2, OCC_ACT_RELU = 3, OCC_ACT_TANH = 4,
                OCC_ACT_GELU_GRAD = 5 /* occ_gemm epilogue: (acc+bias) * gelu'(aux) */ };
 
@@ -122,10 +124,23 @@ typedef struct occ_gemm_desc {
     /* optional bf16 side tensor addressed like C (same row map): with act = OCC_ACT_GELU the pre-activation (acc+bias) is
      * stored to it (saved for backward); with act = OCC_ACT_GELU_GRAD it is read (the saved pre-activation).  NULL = unused. */
     void* aux;
+    /* fp8 operands (ab_dtype OCC_FP8_*): device scalars 1/scale of the per-tensor quantisation of A and W; the accumulator is
+     * multiplied by alpha * (*a_dequant) * (*w_dequant) before bias.  NULL = 1.                                           */
+    const float* a_dequant; const float* w_dequant;
 } occ_gemm_desc;
 /* C = act(alpha * A.W^T + bias) + R.  Replaces every nn.Linear / Conv1d of the path
  * (fairseq wav2vec2 layers reached from sslassist.py:48; AModel.LL sslassist.py:509).             */
 int occ_gemm(const occ_gemm_desc* d, void* stream);
+/* Per-tensor fp8 quantisation with delayed scaling (E4M3 forward / E5M2 gradients).
+ * dst[i] = fp8(src[i] * *scale) saturating at the format's largest finite value (src f32 or bf16, fmt OCC_FP8_E4M3 / OCC_FP8_E5M2);
+ * scale: device scalar or NULL (= 1); amax: device scalar or NULL, raised to max |src[i]| (atomic max) for the NEXT step's scale. */
+int occ_fp8_quantize(const void* src, int src_dtype, void* dst, int fmt, int64_t n, const float* scale, float* amax, void* stream);
+/* amax[i] = max |src| only (current scaling: the first step of a site, weights).                                            */
+int occ_fp8_amax(const void* src, int src_dtype, int64_t n, float* amax, void* stream);
+/* For n sites: scale[i] = fmax / (amax[i] * margin) (1 when amax[i] == 0), inv_scale[i] = 1 / scale[i], amax[i] = 0.
+ * fmax: 448 (e4m3) or 57344 (e5m2).                                                                                          */
+int occ_fp8_update_scales(float* amax, float* scale, float* inv_scale, int64_t n, float fmax, float margin, void* stream);
+
 /* Tuning hook: selects the bf16 kernel family occ_gemm dispatches to (1 = default heuristic; other values force one
  * experimental kernel, see csrc/gemm.hip); v < 0 only queries.  Returns the previous value.  Initialised from the
  * OCC_GEMM_VARIANT environment variable.  Results are identical across variants up to f32 summation order.          */

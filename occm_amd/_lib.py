@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "occ_hip.h")
 
-OCC_F32, OCC_BF16, OCC_F64, OCC_F32_AS_BF16, OCC_AF32_WBF16 = 0, 1, 2, 3, 4
+OCC_F32, OCC_BF16, OCC_F64, OCC_F32_AS_BF16, OCC_AF32_WBF16, OCC_FP8_E4M3, OCC_FP8_E5M2 = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_GELU, ACT_SELU, ACT_RELU, ACT_TANH, ACT_GELU_GRAD = 0, 1, 2, 3, 4, 5
 
 
@@ -31,7 +31,8 @@ class GemmDesc(ctypes.Structure):
                 ("C", ctypes.c_void_p), ("c_map", RowMap), ("c_dtype", ctypes.c_int),
                 ("ab_dtype", ctypes.c_int), ("act", ctypes.c_int), ("alpha", ctypes.c_float),
                 ("n_groups", ctypes.c_int64), ("a_group_stride", ctypes.c_int64),
-                ("w_group_stride", ctypes.c_int64), ("c_group_stride", ctypes.c_int64), ("aux", ctypes.c_void_p)]
+                ("w_group_stride", ctypes.c_int64), ("c_group_stride", ctypes.c_int64), ("aux", ctypes.c_void_p),
+                ("a_dequant", ctypes.c_void_p), ("w_dequant", ctypes.c_void_p)]
 
 
 class GemmTnDesc(ctypes.Structure):

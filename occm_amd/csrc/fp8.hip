@@ -1,0 +1,110 @@
+// Per-tensor fp8 quantisation (OCP e4m3fn / e5m2) with delayed scaling for the fp8 MFMA path of occ_gemm (the
+// XLS-R-1B configuration): quantise with the scale derived from the PREVIOUS step's |max| while recording this step's |max|.
+#include "occ_common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<unsigned short>(const unsigned short* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+
+__device__ __forceinline__ void amax_commit(float m, float* amax) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));   // non-negative floats order as their bit patterns
+}
+
+// E5M2: true -> bf8 (e5m2), false -> fp8 (e4m3fn).  Values are clamped to the largest finite magnitude first (saturating conversion).
+template <typename T, bool E5M2, bool QUANT>
+__global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__ src, unsigned char* __restrict__ dst, long long n, const float* __restrict__ scale,
+                                                           float* __restrict__ amax) {
+    const float sc = QUANT && scale ? *scale : 1.f;
+    const float lim = E5M2 ? 57344.f : 448.f;
+    float mx = 0.f;
+    const long long n8 = n / 8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        float v[8];
+        ld8<T>(src + i * 8, v);
+        unsigned w[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            mx = fmaxf(mx, fmaxf(fabsf(v[e]), fabsf(v[e + 1])));
+            if (QUANT) {
+                const float a = fminf(fmaxf(v[e] * sc, -lim), lim), b = fminf(fmaxf(v[e + 1] * sc, -lim), lim);
+                int cur = (int)w[e >> 2];
+                if (E5M2) cur = (e & 2) ? __builtin_amdgcn_cvt_pk_bf8_f32(a, b, cur, true) : __builtin_amdgcn_cvt_pk_bf8_f32(a, b, cur, false);
+                else cur = (e & 2) ? __builtin_amdgcn_cvt_pk_fp8_f32(a, b, cur, true) : __builtin_amdgcn_cvt_pk_fp8_f32(a, b, cur, false);
+                w[e >> 2] = (unsigned)cur;
+            }
+        }
+        if (QUANT) *reinterpret_cast<uint2*>(dst + i * 8) = make_uint2(w[0], w[1]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {              // tail (n % 8 elements)
+        for (long long i = n8 * 8; i < n; ++i) {
+            const float x = occ_load_f32(src + i);
+            mx = fmaxf(mx, fabsf(x));
+            if (QUANT) {
+                const float a = fminf(fmaxf(x * sc, -lim), lim);
+                const int pk = E5M2 ? __builtin_amdgcn_cvt_pk_bf8_f32(a, 0.f, 0, false) : __builtin_amdgcn_cvt_pk_fp8_f32(a, 0.f, 0, false);
+                dst[i] = (unsigned char)(pk & 0xff);
+            }
+        }
+    }
+    if (amax) amax_commit(mx, amax);
+}
+
+__global__ void fp8_update_scales_kernel(float* __restrict__ amax, float* __restrict__ scale, float* __restrict__ inv, int n, float fmax, float margin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = amax[i];
+    const float sc = a > 0.f ? fmax / (a * margin) : 1.f;
+    scale[i] = sc; inv[i] = 1.f / sc; amax[i] = 0.f;
+}
+
+template <bool QUANT>
+int launch_q(const void* src, int src_dtype, void* dst, int fmt, int64_t n, const float* scale, float* amax, hipStream_t s) {
+    long long blocks = occ_cdiv(occ_cdiv(n, 8), 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+#define OCC_Q(T, E) hipLaunchKernelGGL((fp8_quantize_kernel<T, E, QUANT>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)src, (unsigned char*)dst, (long long)n, scale, amax)
+    if (src_dtype == OCC_F32) { if (fmt == OCC_FP8_E5M2) OCC_Q(float, true); else OCC_Q(float, false); }
+    else { if (fmt == OCC_FP8_E5M2) OCC_Q(unsigned short, true); else OCC_Q(unsigned short, false); }
+#undef OCC_Q
+    return OCC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int occ_fp8_quantize(const void* src, int src_dtype, void* dst, int fmt, int64_t n, const float* scale, float* amax, void* stream) {
+    OCC_CHECK_ARG(src && dst && n >= 1, "occ_fp8_quantize: bad argument");
+    OCC_CHECK_ARG((src_dtype == OCC_F32 || src_dtype == OCC_BF16) && (fmt == OCC_FP8_E4M3 || fmt == OCC_FP8_E5M2), "occ_fp8_quantize: src f32 / bf16, fmt e4m3 / e5m2");
+    OCC_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, "occ_fp8_quantize: alignment");
+    launch_q<true>(src, src_dtype, dst, fmt, n, scale, amax, (hipStream_t)stream);
+    OCC_LAUNCH_CHECK("occ_fp8_quantize");
+    return OCC_OK;
+}
+
+int occ_fp8_amax(const void* src, int src_dtype, int64_t n, float* amax, void* stream) {
+    OCC_CHECK_ARG(src && amax && n >= 1 && (src_dtype == OCC_F32 || src_dtype == OCC_BF16) && ((uintptr_t)src & 15) == 0, "occ_fp8_amax: bad argument");
+    launch_q<false>(src, src_dtype, nullptr, OCC_FP8_E4M3, n, nullptr, amax, (hipStream_t)stream);
+    OCC_LAUNCH_CHECK("occ_fp8_amax");
+    return OCC_OK;
+}
+
+int occ_fp8_update_scales(float* amax, float* scale, float* inv_scale, int64_t n, float fmax, float margin, void* stream) {
+    OCC_CHECK_ARG(amax && scale && inv_scale && n >= 1 && fmax > 0.f && margin > 0.f, "occ_fp8_update_scales: bad argument");
+    hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((unsigned)occ_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, amax, scale, inv_scale, (int)n, fmax, margin);
+    OCC_LAUNCH_CHECK("occ_fp8_update_scales");
+    return OCC_OK;
+}
+
+}  // extern "C"

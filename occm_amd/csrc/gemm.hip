@@ -648,12 +648,14 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     OCC_CHECK_ARG(d, "occ_gemm: null descriptor");
     OCC_CHECK_ARG(d->A && d->W && d->C, "occ_gemm: null operand");
     OCC_CHECK_ARG(d->M >= 1 && d->N >= 1 && d->K >= 1, "occ_gemm: bad shape M=%ld N=%ld K=%ld", (long)d->M, (long)d->N, (long)d->K);
-    OCC_CHECK_ARG(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_F32 || d->ab_dtype == OCC_F32_AS_BF16 || d->ab_dtype == OCC_AF32_WBF16,
-                  "occ_gemm: ab_dtype must be bf16, f32, f32-as-bf16 or af32-wbf16");
+    const bool fp8 = d->ab_dtype == OCC_FP8_E4M3 || d->ab_dtype == OCC_FP8_E5M2;
+    OCC_CHECK_ARG(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_F32 || d->ab_dtype == OCC_F32_AS_BF16 || d->ab_dtype == OCC_AF32_WBF16 || fp8,
+                  "occ_gemm: ab_dtype must be bf16, f32, f32-as-bf16, af32-wbf16 or fp8 (e4m3 / e5m2)");
     OCC_CHECK_ARG(!(d->act == OCC_ACT_GELU_GRAD && !d->aux), "occ_gemm: OCC_ACT_GELU_GRAD needs aux");
     OCC_CHECK_ARG(d->c_dtype == OCC_BF16 || d->c_dtype == OCC_F32, "occ_gemm: c_dtype must be bf16 or f32");
     OCC_CHECK_ARG(!d->R || d->r_dtype == OCC_BF16 || d->r_dtype == OCC_F32, "occ_gemm: r_dtype must be bf16 or f32");
-    const int ce = d->ab_dtype == OCC_F32 ? 4 : 8;            // K granularity: one 16-byte LDS chunk
+    const int ce = d->ab_dtype == OCC_F32 ? 4 : (fp8 ? 16 : 8);            // K granularity: one 16-byte LDS chunk
+    OCC_CHECK_ARG(!fp8 || (d->K % 128 == 0 && d->a_nseg <= 1 && d->n_groups <= 1), "occ_gemm: fp8 needs K %% 128 == 0, one K segment, one group (K=%ld)", (long)d->K);
     OCC_CHECK_ARG(d->K % ce == 0 && d->N % 4 == 0, "occ_gemm: needs K %% %d == 0 and N %% 4 == 0 (K=%ld N=%ld)", ce, (long)d->K, (long)d->N);
     const long long nseg = d->a_nseg > 1 ? d->a_nseg : 1;
     const long long seg_len = nseg > 1 ? d->a_seg_len : d->K;
@@ -677,6 +679,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     a.R = (const char*)d->R; a.rmap = to_rowmap(d->r_map); a.r_dtype = d->r_dtype;
     a.C = (char*)d->C; a.cmap = to_rowmap(d->c_map); a.c_dtype = d->c_dtype;
     a.act = d->act; a.alpha = d->alpha; a.aux = (unsigned short*)d->aux;
+    a.dq_a = fp8 ? d->a_dequant : nullptr; a.dq_w = fp8 ? d->w_dequant : nullptr;
     a.ksplit = 1; a.slabs_per_split = 0; a.ngroups = 1;
     a.dbg = g_dbg;
     a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
@@ -700,6 +703,12 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     // Default for well-filled bf16 launches: the 256x256 eight-phase kernel (gemm_p8.hip).  Measured at M = 12736 (bs 64) against the
     // 128x128 kernels below: fc2 1105 vs 838 TFLOP/s, out-proj 760 vs 633, conv1 1084 vs 881, 4096^3 1248 vs 1058; a launch with fewer
     // than ~0.7 tiles per CU (fc2 at M = 6368: 100 tiles) keeps the small-tile kernels.  OCC_GEMM_P8=0 switches it off.
+    if (fp8) {                                  // the eight-phase kernel is the fp8 path (any size: edge tiles are clamped / masked as for bf16)
+        OCC_CHECK_ARG((d->N * d->ldw) < (1ll << 32), "occ_gemm: fp8 W too large for 32-bit DMA offsets");
+        gemm_p8_launch(a, s, d->ab_dtype == OCC_FP8_E4M3 ? 1 : 2);
+        OCC_LAUNCH_CHECK("occ_gemm");
+        return OCC_OK;
+    }
     static const int p8_env = getenv("OCC_GEMM_P8") ? atoi(getenv("OCC_GEMM_P8")) : 1;
     const long long p8_tiles = occ_cdiv(d->M, 256) * occ_cdiv(d->N, 256);
     const bool x_fits_32bit = true;            // DMA offsets are 32-bit byte offsets from the operand base (checked below)

@@ -21,6 +21,7 @@ struct GemmArgs {
     const char* R; RowMapI rmap; int r_dtype;
     char* C; RowMapI cmap; int c_dtype;
     int act; float alpha;
+    const float* dq_a; const float* dq_w;   // fp8 operands: device scalars that undo the per-tensor quantisation scales (alpha *= *dq_a * *dq_w), or null
     unsigned short* aux;
     int nbm, nbn;
     int group_m;              // >0: walk GROUP_M m-tiles per n-tile before moving on (L2-sized working set), 0: n fastest
@@ -146,6 +147,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 #undef OCC_EPI
         return;
     }
+    const float al = a.alpha * (a.dq_a ? *a.dq_a : 1.f) * (a.dq_w ? *a.dq_w : 1.f);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const long long m = mrow0 + j * 16 + fr;
@@ -158,7 +160,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
             if (n >= a.N) continue;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * a.alpha;
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * al;
             if (breg) {                                                 // bias already in registers (staged through LDS by the caller)
                 v[0] += breg[i][0]; v[1] += breg[i][1]; v[2] += breg[i][2]; v[3] += breg[i][3];
             } else if (a.bias) {
@@ -219,6 +221,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
     const bool plain_c = a.cmap.rpl == 0 && a.cmap.rpb >= a.M, plain_r = !HASR || (a.rmap.rpl == 0 && a.rmap.rpb >= a.M);
     f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (HASB && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+    const float al = a.alpha * (a.dq_a ? *a.dq_a : 1.f) * (a.dq_w ? *a.dq_w : 1.f);       // (1.0 for the bf16 path: the product below is exact)
 #pragma unroll
     for (int ch = 0; ch < NJ / 2; ++ch) {
 #pragma unroll
@@ -232,6 +235,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
             const long long m = mrow0 + ch * 32 + k * 4 + rr;
             if (m >= a.M || n >= a.N) continue;
             const long long coff = (plain_c ? m * a.cmap.rstride : row_off(a.cmap, m)) + n;
+            v = v * al;
             if (HASB) v += bv;
             if (AUXM == 1) {
                 uint2 o;
@@ -265,7 +269,7 @@ template <int NJ>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int lane, long long cshift,
                                                    unsigned char* lds_wave) {
     const int fr = lane & 15, fq = lane >> 4;
-    if (cshift == 0 && a.alpha == 1.0f && (!a.R || a.r_dtype == OCC_F32)) {
+    if (cshift == 0 && (!a.R || a.r_dtype == OCC_F32)) {
         if (a.aux && !a.R && a.c_dtype != OCC_F32) {
             if (a.act == OCC_ACT_GELU && a.bias) { gemm_epilogue_rows_t<NJ, true, true, false, true, 1>(a, acc, mrow0, ncol0, lane, lds_wave); return; }
             if (a.act == OCC_ACT_GELU_GRAD && !a.bias) { gemm_epilogue_rows_t<NJ, false, false, false, true, 2>(a, acc, mrow0, ncol0, lane, lds_wave); return; }
@@ -322,7 +326,7 @@ inline int cu_count() {
 
 
 // 256x256 eight-phase kernel (gemm_p8.hip); the caller has checked: bf16 operands, K % 64 == 0, one K segment, one group
-void gemm_p8_launch(GemmArgs& a, hipStream_t s);
+void gemm_p8_launch(GemmArgs& a, hipStream_t s, int fmt = 0);
 
 // experimental kernels (gemm_family.hip); returns -100 when `variant` is not one of them, else OCC_OK / an error status
 int gemm_family_launch(int variant, GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_t s);

@@ -18,10 +18,18 @@
 //   last; both hold for the leading and the lagging wave row.
 //   The LDS image is lane-linear per DMA instruction (8 rows x 128 B); the bank swizzle chunk ^ (row & 7) is applied to the per-lane
 //   SOURCE chunk and again on the fragment read.
+//
+// FMT: 0 = bf16 operands (v_mfma_f32_16x16x32_bf16, two 32-deep k-steps per 64-element K-tile).  1 / 2 = OCP fp8: W e4m3, X e4m3 (forward)
+// or e5m2 (the gradient operand of an input-gradient GEMM); a K-tile is then 128 elements in the same 128-byte rows, a lane's fragment is
+// 32 consecutive bytes (two ds_read_b128) and the product is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16x16 block with unit block
+// scales (E8M0 127) -- the per-tensor scales of both operands are undone in the epilogue (alpha * dq_a * dq_w).  That instruction takes
+// twice the cycles of the bf16 one for four times the depth: the same loop, twice the FLOPs per K-tile, half the operand bytes per FLOP.
 #include "gemm_common.h"
 #include <type_traits>
 
 namespace occ_gemm_detail {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 #define P8_MFMA(ACC, WF, XF) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WF), __builtin_bit_cast(bf16x8, XF), ACC, 0, 0, 0)
 
@@ -35,6 +43,21 @@ namespace occ_gemm_detail {
     __builtin_amdgcn_s_setprio(0);                                                                 \
     __builtin_amdgcn_sched_barrier(0);
 
+// fp8: 8 MFMAs of depth 128 on the 32-byte fragments.  Inline asm with the accumulator tied in place: through the builtin hipcc gives
+// every result a fresh register quad (the accumulators then do not fit and spill, 420 bytes per lane).  Consecutive MFMAs of one
+// accumulator need no wait states; the epilogue's first VALU read of an accumulator sits behind P8_MFMA_DRAIN.
+#define P8_MFMA_F8(ACC, WF, XF, XT)                                                                                                       \
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] blgp:" #XT : "+v"(ACC) : "v"(WF), "v"(XF), "v"(unit_scales));
+#define P8_QUAD_F8(NH, MH, WQ, XT)                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                 \
+    _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                               \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                           \
+            P8_MFMA_F8(acc[(NH) * 2 + nf][(MH) * 4 + mf], WQ[nf], xq[mf], XT)                      \
+    __builtin_amdgcn_s_setprio(0);                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+#define P8_Q(NH, MH, WQ)                                                                           \
+    if constexpr (FMT == 0) { P8_QUAD(NH, MH, WQ) } else if constexpr (FMT == 1) { P8_QUAD_F8(NH, MH, WQ##q, 0) } else { P8_QUAD_F8(NH, MH, WQ##q, 1) }
+
 #define P8_SYNC_READS()                                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
     __builtin_amdgcn_sched_barrier(0);                                                             \
@@ -45,7 +68,9 @@ namespace occ_gemm_detail {
     __builtin_amdgcn_s_barrier();                                                                  \
     __builtin_amdgcn_sched_barrier(0);
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) {
+template <int FMT>
+__global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
+    constexpr int ES = FMT == 0 ? 2 : 1;           // bytes per operand element; a K-tile is 128 bytes of every row
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 65536];
     const int total = a.nbm * a.nbn;
     const int bid = blockIdx.x;
@@ -69,8 +94,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
     const int wr = wave >> 2, wc = wave & 3;
 
     // ---- LDS-DMA sources: one instruction = 8 rows x 128 B; LDS position p of a row holds source chunk p ^ (row & 7)
+    // (fp8: 32-byte blocks are swizzled whole -- chunk ^ (((row >> 1) & 3) << 1) -- so that a lane's 32-byte fragment stays contiguous
+    // and in k order; the bf16 form swizzles 16-byte chunks)
     const int srow = lane >> 3;
-    const int sch = (lane & 7) ^ srow;
+    const int sch = FMT == 0 ? (lane & 7) ^ srow : (lane & 7) ^ (((srow >> 1) & 3) << 1);
     // 32-bit byte offsets from the (wave-uniform) operand base: the DMA takes its address as SGPR base + VGPR offset, the K advance is scalar
     unsigned soff[4][2];                       // [X0, X1, W0, W1][pass]
 #pragma unroll
@@ -78,9 +105,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             long long m = m0 + q * 128 + h * 64 + wave * 8 + srow; if (m > a.M - 1) m = a.M - 1;
-            soff[h][q] = (unsigned)(row_off(a.xmap, m) * 2 + sch * 16);
+            soff[h][q] = (unsigned)(row_off(a.xmap, m) * ES + sch * 16);
             long long n = n0 + (q * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + srow; if (n > a.N - 1) n = a.N - 1;
-            soff[2 + h][q] = (unsigned)(n * a.ldw * 2 + sch * 16);
+            soff[2 + h][q] = (unsigned)(n * a.ldw * ES + sch * 16);
         }
     // One LDS-DMA instruction in the SGPR-base + 32-bit-VGPR-offset form (hipcc's builtin keeps a 64-bit address pair per source).  It is
     // invisible to the compiler's s_waitcnt bookkeeping, which is what this loop wants: every wait on it below is hand-counted.
@@ -98,15 +125,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
         dma16(base__, soff[HID][1], dma_dst + (BUF) * 65536 + (HID) * 16384 + 8192);                                                   \
     }
 
-    // ---- fragment read addresses (byte addresses in LDS): row fr of a 16-row block, chunk (ks*4 + fq) ^ (fr & 7)
+    // ---- fragment read addresses (byte addresses in LDS): row fr of a 16-row block; bf16: chunk (ks*4 + fq) ^ (fr & 7) for k-step ks,
+    // fp8: the two chunks (2*fq + c) ^ (fr & 7) of the lane's 32 consecutive bytes
     const int fr = lane & 15, fq = lane >> 4;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)lds;
     const unsigned cb = (unsigned)((fq ^ (fr & 7)) << 4);
-    unsigned xa[2][2], wa[2][2];               // [buffer][k-step]
+    constexpr unsigned SECOND = 64u;
+    unsigned xa[2][2], wa[2][2];               // [buffer][k-step (bf16) / 16-byte half (fp8)]
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        xa[b][0] = lds0 + b * 65536 + (wr * 64 + fr) * 128 + cb;          xa[b][1] = xa[b][0] ^ 64u;
-        wa[b][0] = lds0 + b * 65536 + 32768 + (wc * 32 + fr) * 128 + cb;  wa[b][1] = wa[b][0] ^ 64u;
+        xa[b][0] = lds0 + b * 65536 + (wr * 64 + fr) * 128 + cb;          xa[b][1] = xa[b][0] ^ SECOND;
+        wa[b][0] = lds0 + b * 65536 + 32768 + (wc * 32 + fr) * 128 + cb;  wa[b][1] = wa[b][0] ^ SECOND;
     }
 
     f32x4 acc[4][8];                           // [16-column block of the wave's 64][16-row block of its 128]
@@ -115,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (int)(a.K / 64);
+    const int nt = (int)(a.K / (128 / ES));
     // ---- prologue: all of K-tile 0, three half-tiles of K-tile 1
     P8_STAGE(2, 0, 0) P8_STAGE(0, 0, 0) P8_STAGE(3, 0, 0) P8_STAGE(1, 0, 0)
     if (nt > 1) {
@@ -133,37 +162,59 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
     const unsigned long long dg_t1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    u32x4 w0[2][2], w1[2][2], x[4][2];         // [16-row block][k-step]
+    u32x4 w0[2][2], w1[2][2], x[4][2];         // bf16: [16-row block][k-step]
+    i32x8 w0q[2], w1q[2], xq[4];               // fp8: [16-row block], 32 consecutive bytes of the row per lane
+    const int unit_scales = 0x7f7f7f7f;        // E8M0 block scales of 1.0 for both operands
+    // fp8 fragments are plain 32-byte LDS loads (the DMA is inline asm, so the compiler sees no pending LDS writes to wait for): byte
+    // offset of this lane's block in row fr of a 16-row group
+    const unsigned f8x = (unsigned)((wr * 64 + fr) * 128 + ((fq ^ ((fr >> 1) & 3)) << 5));
+    const unsigned f8w = (unsigned)(32768 + (wc * 32 + fr) * 128 + ((fq ^ ((fr >> 1) & 3)) << 5));
+#define P8_LD8(OFF) (*reinterpret_cast<const i32x8*>(lds + (OFF)))
     auto tile = [&](auto bufc, const int t) {
         constexpr int B = decltype(bufc)::value;
         // -------- P1
+        if constexpr (FMT == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { w0[0][ks] = ds_read128<0>(wa[B][ks]); w0[1][ks] = ds_read128<2048>(wa[B][ks]); }
+            for (int ks = 0; ks < 2; ++ks) { w0[0][ks] = ds_read128<0>(wa[B][ks]); w0[1][ks] = ds_read128<2048>(wa[B][ks]); }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            x[0][ks] = ds_read128<0>(xa[B][ks]); x[1][ks] = ds_read128<2048>(xa[B][ks]);
-            x[2][ks] = ds_read128<4096>(xa[B][ks]); x[3][ks] = ds_read128<6144>(xa[B][ks]);
+            for (int ks = 0; ks < 2; ++ks) {
+                x[0][ks] = ds_read128<0>(xa[B][ks]); x[1][ks] = ds_read128<2048>(xa[B][ks]);
+                x[2][ks] = ds_read128<4096>(xa[B][ks]); x[3][ks] = ds_read128<6144>(xa[B][ks]);
+            }
+        } else {
+            w0q[0] = P8_LD8(B * 65536 + f8w); w0q[1] = P8_LD8(B * 65536 + f8w + 2048);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) xq[mf] = P8_LD8(B * 65536 + f8x + mf * 2048);
         }
         if (t + 1 < nt) P8_STAGE(1, B ^ 1, t + 1)
         P8_SYNC_READS()
-        P8_QUAD(0, 0, w0)
+        P8_Q(0, 0, w0)
         P8_END_PHASE()
         // -------- P2
+        if constexpr (FMT == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { w1[0][ks] = ds_read128<16384>(wa[B][ks]); w1[1][ks] = ds_read128<16384 + 2048>(wa[B][ks]); }
+            for (int ks = 0; ks < 2; ++ks) { w1[0][ks] = ds_read128<16384>(wa[B][ks]); w1[1][ks] = ds_read128<16384 + 2048>(wa[B][ks]); }
+        } else {
+            w1q[0] = P8_LD8(B * 65536 + f8w + 16384); w1q[1] = P8_LD8(B * 65536 + f8w + 16384 + 2048);
+        }
         if (t + 2 < nt) P8_STAGE(2, B, t + 2)
         P8_SYNC_READS()
-        P8_QUAD(1, 0, w1)
+        P8_Q(1, 0, w1)
         P8_END_PHASE()
         // -------- P3
+        if constexpr (FMT == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            x[0][ks] = ds_read128<16384>(xa[B][ks]); x[1][ks] = ds_read128<16384 + 2048>(xa[B][ks]);
-            x[2][ks] = ds_read128<16384 + 4096>(xa[B][ks]); x[3][ks] = ds_read128<16384 + 6144>(xa[B][ks]);
+            for (int ks = 0; ks < 2; ++ks) {
+                x[0][ks] = ds_read128<16384>(xa[B][ks]); x[1][ks] = ds_read128<16384 + 2048>(xa[B][ks]);
+                x[2][ks] = ds_read128<16384 + 4096>(xa[B][ks]); x[3][ks] = ds_read128<16384 + 6144>(xa[B][ks]);
+            }
+        } else {
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) xq[mf] = P8_LD8(B * 65536 + f8x + 16384 + mf * 2048);
         }
         if (t + 2 < nt) P8_STAGE(0, B, t + 2)
         P8_SYNC_READS()
-        P8_QUAD(1, 1, w1)
+        P8_Q(1, 1, w1)
         P8_END_PHASE()
         // -------- P4
         if (t + 2 < nt) {
@@ -175,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        P8_QUAD(0, 1, w0)
+        P8_Q(0, 1, w0)
         P8_END_PHASE()
     };
     int t = 0;
@@ -186,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
     if (t < nt) tile(std::integral_constant<int, 0>{}, t);
     if (wr == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }        // pairs with the lagging row's last barrier
 
+    if constexpr (FMT != 0) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last asm MFMAs' results -> the epilogue's VALU reads
 #ifdef P8_DIAG
     const unsigned long long dg_t2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -200,12 +252,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const GemmArgs a) 
 #endif
 }
 
-// Launch helper used by occ_gemm.  Preconditions (checked by the caller): bf16 operands, K % 64 == 0, one K segment, one group.
-void gemm_p8_launch(GemmArgs& a, hipStream_t s) {
+// Launch helper used by occ_gemm.  Preconditions (checked by the caller): bf16 operands and K % 64 == 0, or fp8 operands (fmt 1: A e4m3,
+// fmt 2: A e5m2; W e4m3) and K % 128 == 0; one K segment, one group.
+void gemm_p8_launch(GemmArgs& a, hipStream_t s, int fmt) {
     a.nbm = (int)occ_cdiv(a.M, 256);
     a.nbn = (int)occ_cdiv(a.N, 256);
     a.group_m = a.nbm >= 8 ? 8 : 0;
-    hipLaunchKernelGGL(gemm_bf16_p8_kernel, dim3((unsigned)((long long)a.nbm * a.nbn)), dim3(512), 0, s, a);
+    const dim3 grid((unsigned)((long long)a.nbm * a.nbn));
+    if (fmt == 0) hipLaunchKernelGGL(gemm_p8_kernel<0>, grid, dim3(512), 0, s, a);
+    else if (fmt == 1) hipLaunchKernelGGL(gemm_p8_kernel<1>, grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(gemm_p8_kernel<2>, grid, dim3(512), 0, s, a);
 }
 
 }  // namespace occ_gemm_detail

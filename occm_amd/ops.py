@@ -28,7 +28,7 @@ def rowmap(rows_per_batch, batch_stride, row_stride, rows_per_line=0, line_strid
 
 
 def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, act=ACT_NONE, alpha=1.0,
-             R=None, r_map=None, r_dtype=OCC_F32, a_seg=None, groups=None, aux=None):
+             R=None, r_map=None, r_dtype=OCC_F32, a_seg=None, groups=None, aux=None, a_dequant=None, w_dequant=None):
     """Direct descriptor-level call.  A/W/C/R/bias are ints (device addresses) or tensors."""
     d = GemmDesc()
     d.M, d.N, d.K = int(M), int(N), int(K)
@@ -55,12 +55,16 @@ def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, 
         d.n_groups, d.a_group_stride, d.w_group_stride, d.c_group_stride = [int(v) for v in groups]
     if aux is not None:
         d.aux = aux if isinstance(aux, int) else aux.data_ptr()
+    if a_dequant is not None:
+        d.a_dequant = a_dequant if isinstance(a_dequant, int) else a_dequant.data_ptr()
+    if w_dequant is not None:
+        d.w_dequant = w_dequant if isinstance(w_dequant, int) else w_dequant.data_ptr()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib().occ_gemm(ctypes.byref(d), stream_ptr()), "occ_gemm")
         e1.record()
-        PROFILE.append(("gemm_bf16" if ab_dtype in (OCC_BF16, OCC_AF32_WBF16) else "gemm_f32", e0, e1))
+        PROFILE.append(("gemm_bf16" if ab_dtype in (OCC_BF16, OCC_AF32_WBF16, _lib.OCC_FP8_E4M3, _lib.OCC_FP8_E5M2) else "gemm_f32", e0, e1))
         return
     check(lib().occ_gemm(ctypes.byref(d), stream_ptr()), "occ_gemm")
 
@@ -146,6 +150,23 @@ def transpose_bf16_rows(src, src_map, dst, rows, cols, ld_dst, colsum=None, src_
     check(lib().occ_transpose_bf16_rows(_p(src), sd, ctypes.byref(src_map), _p(dst), int(rows), int(cols), int(ld_dst), _p(colsum), stream_ptr()),
           "occ_transpose_bf16_rows")
     return dst
+
+
+FP8_MAX = {_lib.OCC_FP8_E4M3: 448.0, _lib.OCC_FP8_E5M2: 57344.0}
+
+
+def fp8_quantize(src, dst, fmt, scale=None, amax=None):
+    """dst (uint8, src.numel()) = fp8(src * scale); amax (device scalar) is raised to max |src|."""
+    check(lib().occ_fp8_quantize(ptr(src), dtype_code(src), ptr(dst), int(fmt), src.numel(), ptr(scale), ptr(amax), stream_ptr()), "occ_fp8_quantize")
+    return dst
+
+
+def fp8_amax(src, amax):
+    check(lib().occ_fp8_amax(ptr(src), dtype_code(src), src.numel(), ptr(amax), stream_ptr()), "occ_fp8_amax")
+
+
+def fp8_update_scales(amax, scale, inv_scale, fmt, margin=1.0):
+    check(lib().occ_fp8_update_scales(ptr(amax), ptr(scale), ptr(inv_scale), amax.numel(), FP8_MAX[fmt], float(margin), stream_ptr()), "occ_fp8_update_scales")
 
 
 def dropout_ex(x, y, mask, p, seed=0, stream_id=0, generate=False, residual=None, scale=1.0):

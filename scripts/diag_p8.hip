@@ -31,9 +31,9 @@ int main() {
         hipMalloc(&dg, nwg * 6 * 8);
         a.diag = dg;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int w = 0; w < 20; ++w) hipLaunchKernelGGL(gemm_bf16_p8_kernel, dim3(nwg), dim3(512), 0, 0, a);
+        for (int w = 0; w < 20; ++w) hipLaunchKernelGGL(gemm_p8_kernel<0>, dim3(nwg), dim3(512), 0, 0, a);
         hipEventRecord(e0);
-        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(gemm_bf16_p8_kernel, dim3(nwg), dim3(512), 0, 0, a);
+        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(gemm_p8_kernel<0>, dim3(nwg), dim3(512), 0, 0, a);
         hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         std::vector<unsigned long long> h(nwg * 6);
