@@ -437,6 +437,10 @@ class XlsrFineTuner(XlsrFrontend):
             shp = self.tslots[name][1]
             if name.endswith(".w"):
                 ops.transpose_bf16(self.mp[name], self.wT[name], shp[0], shp[1], ld_src=shp[1], ld_dst=shp[0])
+        if getattr(self, "fp8", False):
+            self._fp8_weights()
+            if self.ctx is None and self.drop_step > 0:
+                self.f8["warm"] = False                          # a whole step has been seen: every site has a measured |max|
 
     def export_params(self):
         """Trainable tensors back under their fairseq names (q/k/v split again)."""
@@ -488,6 +492,81 @@ class XlsrFineTuner(XlsrFrontend):
             tr["du"], tr["dh"], tr["da"], tr["dqkv"] = e(M, Fd), e(M, D), e(M, D), e(M, 3 * D)
             ws["tr"] = tr
         return ws
+
+    # ---- fp8 transformer GEMMs ---------------------------------------------------------------------------
+    _E4 = {"h1": 0, "att": 1, "h2": 2, "f": 3, "qkv.w": 4, "o.w": 5, "fc1.w": 6, "fc2.w": 7}
+    _E5 = {"g_qkv": 0, "g_o": 1, "g_fc1": 2, "g_fc2": 3}
+
+    def enable_fp8(self, margin=1.0):
+        """Forward and input-gradient GEMMs of the transformer layers on the fp8 MFMA path: activations and weights e4m3, gradients
+        e5m2, per-tensor scales.  Activation / gradient sites use DELAYED scaling (this step's scale comes from the previous step's
+        |max|; the first step measures |max| before quantising), weights are re-quantised from their bf16 mirrors with their current
+        |max| after every optimizer step.  Weight gradients, attention, LayerNorm and the conv / projection prefix stay bf16."""
+        from .._lib import OCC_FP8_E4M3, OCC_FP8_E5M2
+        cfg, dev = self.cfg, self.device
+        n = cfg.layers
+        z = lambda k: torch.zeros(k, device=dev, dtype=torch.float32)
+        self.f8 = {"e4": OCC_FP8_E4M3, "e5": OCC_FP8_E5M2, "margin": margin, "warm": True,
+                   "amax4": z(n * 8), "scale4": torch.ones(n * 8, device=dev), "inv4": torch.ones(n * 8, device=dev),
+                   "amax5": z(n * 4), "scale5": torch.ones(n * 4, device=dev), "inv5": torch.ones(n * 4, device=dev), "wq": {}, "wtq": {}, "qa": None, "qg": None}
+        for i in range(n):
+            for wn in ("qkv.w", "o.w", "fc1.w", "fc2.w"):
+                name = "l%d.%s" % (i, wn)
+                self.f8["wq"][name] = torch.empty(self.w[name].shape, device=dev, dtype=torch.uint8)
+                self.f8["wtq"][name] = torch.empty(self.wT[name].shape, device=dev, dtype=torch.uint8)
+        self.fp8 = True
+        self._fp8_weights()
+
+    def _fp8_weights(self):
+        """Weights: |max| of the bf16 mirror now -> scale -> e4m3 copies of W and W^T (same scale)."""
+        f8 = self.f8
+        for name in f8["wq"]:
+            i, wn = int(name[1:name.index(".")]), name[name.index(".") + 1:]
+            k = i * 8 + self._E4[wn]
+            ops.fp8_amax(self.w[name], f8["amax4"][k:k + 1])
+        # one pass over every e4m3 / e5m2 site: the activation and gradient sites pick up this step's |max| for the next step
+        ops.fp8_update_scales(f8["amax4"], f8["scale4"], f8["inv4"], f8["e4"], f8["margin"])
+        ops.fp8_update_scales(f8["amax5"], f8["scale5"], f8["inv5"], f8["e5"], f8["margin"])
+        for name in f8["wq"]:
+            i, wn = int(name[1:name.index(".")]), name[name.index(".") + 1:]
+            k = i * 8 + self._E4[wn]
+            ops.fp8_quantize(self.w[name], f8["wq"][name], f8["e4"], scale=f8["scale4"][k:k + 1])
+            ops.fp8_quantize(self.wT[name], f8["wtq"][name], f8["e4"], scale=f8["scale4"][k:k + 1])
+
+    def _fp8_q(self, x, kind, k):
+        """x (bf16 / f32) -> fp8 scratch; kind 4 = e4m3 activation site, 5 = e5m2 gradient site; returns (buffer, inverse-scale scalar)."""
+        f8 = self.f8
+        fmt, am, sc, inv = (f8["e4"], f8["amax4"], f8["scale4"], f8["inv4"]) if kind == 4 else (f8["e5"], f8["amax5"], f8["scale5"], f8["inv5"])
+        key = "qa" if kind == 4 else "qg"
+        if f8[key] is None or f8[key].numel() < x.numel():
+            f8[key] = torch.empty(x.numel(), device=self.device, dtype=torch.uint8)
+        q = f8[key][: x.numel()]
+        if f8["warm"]:                                           # no history yet: measure, derive the scale, then quantise (current scaling)
+            ops.fp8_amax(x, am[k:k + 1])
+            ops.fp8_update_scales(am[k:k + 1], sc[k:k + 1], inv[k:k + 1], fmt, f8["margin"])
+        ops.fp8_quantize(x, q, fmt, scale=sc[k:k + 1], amax=am[k:k + 1])
+        return q, inv[k:k + 1]
+
+    def _lin(self, i, wn, a, site, M, N, K, C, c_map, c_dtype, **kw):
+        """Forward Linear of layer i (weight "l<i>.<wn>", input a [M,K] bf16): bf16 MFMA, or fp8 with the site's delayed scale."""
+        name = "l%d.%s" % (i, wn)
+        if not getattr(self, "fp8", False):
+            ops.gemm_raw(M, N, K, a, rowmap(M, 0, K), self.w[name], K, C, c_map, c_dtype, OCC_BF16_CODE, **kw)
+            return
+        q, inv_a = self._fp8_q(a, 4, i * 8 + self._E4[site])
+        kw_ = i * 8 + self._E4[wn]
+        ops.gemm_raw(M, N, K, q, rowmap(M, 0, K), self.f8["wq"][name], K, C, c_map, c_dtype, self.f8["e4"], a_dequant=inv_a, w_dequant=self.f8["inv4"][kw_:kw_ + 1], **kw)
+
+    def _dgrad(self, i, wn, dy, gsite, M, N, K, C, **kw):
+        """Input gradient dX [M,N] = dY [M,K] . W (through W^T [N,K]) of layer i's weight wn."""
+        name = "l%d.%s" % (i, wn)
+        if not getattr(self, "fp8", False):
+            ops.gemm_raw(M, N, K, dy, rowmap(M, 0, K), self.wT[name], K, C, rowmap(M, 0, N), OCC_BF16_CODE, OCC_BF16_CODE, **kw)
+            return
+        q, inv_g = self._fp8_q(dy, 5, i * 4 + self._E5[gsite])
+        kw_ = i * 8 + self._E4[wn]
+        ops.gemm_raw(M, N, K, q, rowmap(M, 0, K), self.f8["wtq"][name], K, C, rowmap(M, 0, N), OCC_BF16_CODE, self.f8["e5"], a_dequant=inv_g,
+                     w_dequant=self.f8["inv4"][kw_:kw_ + 1], **kw)
 
     # ---- train-mode dropouts ---------------------------------------------------------------------------------------------
     def _p(self, field):
@@ -553,22 +632,22 @@ class XlsrFineTuner(XlsrFrontend):
                 x_next.copy_(x_in)
                 continue
             ops.layernorm(x_in, w["l%d.ln1.g" % i], w["l%d.ln1.b" % i], out=s["h1"])
-            ops.linear(s["h1"], w["l%d.qkv.w" % i], w["l%d.qkv.b" % i], out=s["qkv"])
+            self._lin(i, "qkv.w", s["h1"], "h1", M, 3 * D, D, s["qkv"], rowmap(M, 0, 3 * D), code, bias=w["l%d.qkv.b" % i])
             ops.attention(s["qkv"], B, T, cfg.heads, hd, hd ** -0.5, out=s["att"], lse=s["lse"])
             if p_res > 0:                                        # x = residual + dropout1(self_attn(LN(x)))
-                ops.gemm_raw(M, D, D, s["att"], xmap, w["l%d.o.w" % i], D, tr["y"], xmap, OCC_F32, code, bias=w["l%d.o.b" % i])
+                self._lin(i, "o.w", s["att"], "att", M, D, D, tr["y"], xmap, OCC_F32, bias=w["l%d.o.b" % i])
                 self._drop_fwd("l%d.d1" % i, tr["y"], x_mid, p_res, residual=x_in)
             else:
-                ops.gemm_raw(M, D, D, s["att"], xmap, w["l%d.o.w" % i], D, x_mid, xmap, OCC_F32, code, bias=w["l%d.o.b" % i], R=x_in, r_map=xmap, r_dtype=OCC_F32)
+                self._lin(i, "o.w", s["att"], "att", M, D, D, x_mid, xmap, OCC_F32, bias=w["l%d.o.b" % i], R=x_in, r_map=xmap, r_dtype=OCC_F32)
             ops.layernorm(x_mid, w["l%d.ln2.g" % i], w["l%d.ln2.b" % i], out=s["h2"])
-            ops.gemm_raw(M, Fd, D, s["h2"], xmap, w["l%d.fc1.w" % i], D, s["f"], rowmap(M, 0, Fd), code, code, bias=w["l%d.fc1.b" % i], act=ACT_GELU, aux=s["u"])
+            self._lin(i, "fc1.w", s["h2"], "h2", M, Fd, D, s["f"], rowmap(M, 0, Fd), code, bias=w["l%d.fc1.b" % i], act=ACT_GELU, aux=s["u"])
             if p_act > 0:                                        # dropout2 on the activation
                 self._drop_fwd("l%d.act" % i, s["f"], s["f"], p_act)
             if p_res > 0:                                        # x = residual + dropout3(fc2(.))
-                ops.gemm_raw(M, D, Fd, s["f"], rowmap(M, 0, Fd), w["l%d.fc2.w" % i], Fd, tr["y"], xmap, OCC_F32, code, bias=w["l%d.fc2.b" % i])
+                self._lin(i, "fc2.w", s["f"], "f", M, D, Fd, tr["y"], xmap, OCC_F32, bias=w["l%d.fc2.b" % i])
                 self._drop_fwd("l%d.d3" % i, tr["y"], x_next, p_res, residual=x_mid)
             else:
-                ops.gemm_raw(M, D, Fd, s["f"], rowmap(M, 0, Fd), w["l%d.fc2.w" % i], Fd, x_next, xmap, OCC_F32, code, bias=w["l%d.fc2.b" % i], R=x_mid, r_map=xmap, r_dtype=OCC_F32)
+                self._lin(i, "fc2.w", s["f"], "f", M, D, Fd, x_next, xmap, OCC_F32, bias=w["l%d.fc2.b" % i], R=x_mid, r_map=xmap, r_dtype=OCC_F32)
         out = torch.empty(B, T, D, device=self.device, dtype=torch.float32)
         ops.layernorm(tr["x_out"], w["enc_ln.g"], w["enc_ln.b"], out=out.view(M, D))
         self.ctx = (B, L)
@@ -649,21 +728,21 @@ class XlsrFineTuner(XlsrFrontend):
             if p_res > 0:
                 dyb = tr["dyb"]; self._drop_bwd("l%d.d3" % i, dxb, dyb, p_res)
             self._wgrad(dyb, s["f"], D, Fd, M, "l%d.fc2.w" % i, "l%d.fc2.b" % i)
-            ops.gemm_raw(M, Fd, D, dyb, xmap, self.wT["l%d.fc2.w" % i], D, tr["du"], fmap, bfc, bfc, act=ACT_GELU_GRAD, aux=s["u"])
+            self._dgrad(i, "fc2.w", dyb, "g_fc2", M, Fd, D, tr["du"], act=ACT_GELU_GRAD, aux=s["u"])
             if p_act > 0:                                        # (elementwise factors commute: mask after GELU')
                 self._drop_bwd("l%d.act" % i, tr["du"], tr["du"], p_act)
             self._wgrad(tr["du"], s["h2"], Fd, D, M, "l%d.fc1.w" % i, "l%d.fc1.b" % i)
-            ops.gemm_raw(M, D, Fd, tr["du"], fmap, self.wT["l%d.fc1.w" % i], Fd, tr["dh"], xmap, bfc, bfc)
+            self._dgrad(i, "fc1.w", tr["du"], "g_fc1", M, D, Fd, tr["dh"])
             ops.layernorm_bwd(tr["dh"], s["x_mid"], w["l%d.ln2.g" % i], dx, dx, self.mg["l%d.ln2.g" % i], self.mg["l%d.ln2.b" % i], dx_bf16=dxb)
             # ---- attention: x_mid = x_in + dropout1(out_proj(attn(qkv(LN1(x_in)))))
             dyb = dxb
             if p_res > 0:
                 dyb = tr["dyb"]; self._drop_bwd("l%d.d1" % i, dxb, dyb, p_res)
             self._wgrad(dyb, s["att"], D, D, M, "l%d.o.w" % i, "l%d.o.b" % i)
-            ops.gemm_raw(M, D, D, dyb, xmap, self.wT["l%d.o.w" % i], D, tr["da"], xmap, bfc, bfc)
+            self._dgrad(i, "o.w", dyb, "g_o", M, D, D, tr["da"])
             ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
             self._wgrad(tr["dqkv"], s["h1"], 3 * D, D, M, "l%d.qkv.w" % i, "l%d.qkv.b" % i)
-            ops.gemm_raw(M, D, 3 * D, tr["dqkv"], qmap, self.wT["l%d.qkv.w" % i], 3 * D, tr["dh"], xmap, bfc, bfc)
+            self._dgrad(i, "qkv.w", tr["dqkv"], "g_qkv", M, D, 3 * D, tr["dh"])
             ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i], dx_bf16=dxb)
             if grad_ready is not None:
                 grad_ready(*self.layer_grad_range(i))
