@@ -16,9 +16,19 @@ template <> __device__ __forceinline__ void ld8<unsigned short>(const unsigned s
     for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
 }
 
+// One atomic per WORKGROUP, and only when the workgroup's maximum beats the value currently in memory: atomics on one address retire
+// at ~12 ns each (MI355X_MICROARCH.md, fan-in), so the first version's 16 k per-wave atomics were 190 us of a 200 us launch.  The
+// plain pre-read can be stale, which only costs an unnecessary (still correct) atomic.
 __device__ __forceinline__ void amax_commit(float m, float* amax) {
+    __shared__ float wm[4];
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));   // non-negative floats order as their bit patterns
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));   // non-negative floats order as their bit patterns
+    }
 }
 
 // E5M2: true -> bf8 (e5m2), false -> fp8 (e4m3fn).  Values are clamped to the largest finite magnitude first (saturating conversion).
@@ -71,7 +81,7 @@ __global__ void fp8_update_scales_kernel(float* __restrict__ amax, float* __rest
 template <bool QUANT>
 int launch_q(const void* src, int src_dtype, void* dst, int fmt, int64_t n, const float* scale, float* amax, hipStream_t s) {
     long long blocks = occ_cdiv(occ_cdiv(n, 8), 256);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
 #define OCC_Q(T, E) hipLaunchKernelGGL((fp8_quantize_kernel<T, E, QUANT>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)src, (unsigned char*)dst, (long long)n, scale, amax)
     if (src_dtype == OCC_F32) { if (fmt == OCC_FP8_E5M2) OCC_Q(float, true); else OCC_Q(float, false); }
