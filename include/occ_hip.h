@@ -141,13 +141,10 @@ int occ_fp8_amax(const void* src, int src_dtype, int64_t n, float* amax, void* s
  * fmax: 448 (e4m3) or 57344 (e5m2).                                                                                          */
 int occ_fp8_update_scales(float* amax, float* scale, float* inv_scale, int64_t n, float fmax, float margin, void* stream);
 
-/* Tuning hook: selects the bf16 kernel family occ_gemm dispatches to (1 = default heuristic; other values force one
- * experimental kernel, see csrc/gemm.hip); v < 0 only queries.  Returns the previous value.  Initialised from the
- * OCC_GEMM_VARIANT environment variable.  Results are identical across variants up to f32 summation order.          */
+/* Tuning hook: forces one kernel of the bf16 GEMM family instead of the size heuristic (1 = heuristic, the default; 30 = the
+ * 256x256 eight-phase kernel; 3 = 256x128 LDS-DMA tile; 14 = half-slab pipeline; 22 = in-workgroup split-K); v < 0 only queries.
+ * Returns the previous value.  Initialised from OCC_GEMM_VARIANT.  Results agree across kernels up to f32 summation order.  */
 int occ_gemm_variant(int v);
-/* Ablation bits for timing experiments (1: no operand loads in the K loop, 2: no MFMA, 4: no fragment reads); results are
- * WRONG while any bit is set.  bits < 0 only queries; returns the previous value.  Never set by the product code.        */
-int occ_gemm_debug(int bits);
 
 
 /* Weight-gradient GEMM (f32): C[n1,n2] += alpha * sum_m A[m,n1] * B[m,n2]; A rows [N1] and B rows [N2] go through

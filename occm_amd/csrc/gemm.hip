@@ -445,101 +445,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two-wave form of the 128x128 tile (experiment, variant 19): the same LDS image and DMA staging, but each of TWO waves owns 128 rows x
-// 64 columns (32 accumulators) instead of four waves owning 64x64: 8 + 4 fragment reads per 32 MFMAs instead of 4 + 4 per 16 (25 % fewer
-// ds_read bytes per FLOP), 8 waves per CU instead of 16.  Measured 7-25 % SLOWER than the default on every front-end shape: the default has
-// no software pipelining (wait for the slab, multiply it), so its speed comes from the other 3 waves of a SIMD running while one waits, and
-// halving the waves costs more than the lighter LDS traffic returns (LDS counters on the default: no bank conflicts, LDS array ~15 % busy).
-template <bool SPLITK = false>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_dma2_kernel(const GemmArgs a) {
-    constexpr int ES = 2, CE = 8, SLAB_K = 64, TMT = 128;
-    constexpr int NT = 128, RPP = NT / 8, XP = TMT / RPP, WP = TN / RPP;
-    __shared__ uint4 lds[(TMT + TN) * CHUNKS];
-    uint4* ldsX = lds; uint4* ldsW = lds + TMT * CHUNKS;
-    const int total = a.nbm * a.nbn * (SPLITK ? a.ksplit : 1);
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
-    const int vid_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int kpart = SPLITK ? vid_all % a.ksplit : 0;
-    const int vid = SPLITK ? vid_all / a.ksplit : vid_all;
-    int tile_n = vid % a.nbn, tile_m = vid / a.nbn;
-    if (a.group_m > 0) {
-        const int per_group = a.group_m * a.nbn;
-        const int gid = vid / per_group, first_m = gid * a.group_m;
-        const int gsz = a.nbm - first_m < a.group_m ? a.nbm - first_m : a.group_m;
-        const int loc = vid - gid * per_group;
-        tile_m = first_m + loc % gsz;
-        tile_n = loc / gsz;
-    }
-    const long long m0 = (long long)tile_m * TMT, n0 = (long long)tile_n * TN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long grp = blockIdx.y;
-    const char* Xg = a.X + grp * a.a_gstride * ES;
-    const char* Wg = a.W + grp * a.w_gstride * ES;
-    const long long cshift = grp * a.c_gstride;
-    const int pos = tid & 7, srow = tid >> 3;
-    const char* xsrc[XP]; const char* wsrc[WP];
-    const int ck = pos ^ (srow & 7);                 // RPP % 8 == 0: the same source chunk in every pass
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-        long long m = m0 + srow + RPP * i; if (m > a.M - 1) m = a.M - 1;
-        xsrc[i] = Xg + row_off(a.xmap, m) * ES;
-    }
-#pragma unroll
-    for (int i = 0; i < WP; ++i) {
-        long long n = n0 + srow + RPP * i; if (n > a.N - 1) n = a.N - 1;
-        wsrc[i] = Wg + n * a.ldw * ES;
-    }
-    const int nslab_all = (int)(a.K / SLAB_K);
-    const int slab0 = SPLITK ? kpart * a.slabs_per_split : 0;
-    const int nslab = SPLITK ? (slab0 + a.slabs_per_split < nslab_all ? slab0 + a.slabs_per_split : nslab_all) : nslab_all;
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fq = lane >> 4;
-    for (int slab = slab0; slab < nslab; ++slab) {
-        const long long k0 = (long long)slab * SLAB_K + ck * CE;
-        long long kx = k0;
-        if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
-#pragma unroll
-        for (int i = 0; i < XP; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + kx * ES), (lds_void*)&ldsX[(wave * 8 + RPP * i) * CHUNKS], 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < WP; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + k0 * ES), (lds_void*)&ldsW[(wave * 8 + RPP * i) * CHUNKS], 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            uint4 wf[4], xf[8];
-            const int chk = kb * 4 + fq;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rw = wave * 64 + i * 16 + fr;
-                wf[i] = ldsW[rw * CHUNKS + (chk ^ (rw & 7))];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int rx = j * 16 + fr;
-                xf[j] = ldsX[rx * CHUNKS + (chk ^ (rx & 7))];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        *reinterpret_cast<bf16x8*>(&wf[i]), *reinterpret_cast<bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    if constexpr (SPLITK) gemm_epilogue_atomic<8>(a, acc, m0, n0 + wave * 64, fr, fq, cshift);
-    else gemm_epilogue<8>(a, acc, m0, n0 + wave * 64, fr, fq, cshift);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Half-slab pipeline (experiment, variant 14): the 32 KiB of the default kernel cut into two 16 KiB halves of K = 32, so that one
+// Half-slab pipeline (occ_gemm_variant 14; the fallback for under-filled long-K launches whose slab count is odd): the 32 KiB of the default kernel cut into two 16 KiB halves of K = 32, so that one
 // half is always in flight while the other is being multiplied -- the default kernel has nothing in flight while it computes.
 // Same occupancy (4 workgroups per CU), twice the barriers.  64-byte LDS rows: chunk c of row r sits at c ^ ((r >> 1) & 3), which is
 // conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32).
@@ -625,7 +531,6 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_hs_kernel(const GemmArgs a) 
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int g_dbg = 0;
 int g_variant = getenv("OCC_GEMM_VARIANT") ? atoi(getenv("OCC_GEMM_VARIANT")) : 1;
 
 }  // namespace occ_gemm_detail
@@ -635,12 +540,6 @@ using namespace occ_gemm_detail;
 extern "C" int occ_gemm_variant(int v) {
     const int prev = g_variant;
     if (v >= 0) g_variant = v;
-    return prev;
-}
-
-extern "C" int occ_gemm_debug(int bits) {
-    const int prev = g_dbg;
-    if (bits >= 0) g_dbg = bits;
     return prev;
 }
 
@@ -681,7 +580,6 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     a.act = d->act; a.alpha = d->alpha; a.aux = (unsigned short*)d->aux;
     a.dq_a = fp8 ? d->a_dequant : nullptr; a.dq_w = fp8 ? d->w_dequant : nullptr;
     a.ksplit = 1; a.slabs_per_split = 0; a.ngroups = 1;
-    a.dbg = g_dbg;
     a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
     a.tile_rows = TM;
     // grouped tile order (8 m-tiles per W panel) measured +3 % on the N >= 3072 front-end GEMMs and +10 % at 4096^3, -2 % at N = 1024
@@ -698,45 +596,8 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     // 256x128 tiles only pay on large square problems (4096^3: 999 vs 865 TFLOP/s); on the front-end shapes (M = 6368, or N = 512)
     // the 128x128 tile's finer granularity wins by 3-15 % (scripts/bench_gemm.py), so it stays the default there.
     const bool big = d->M >= 4096 && d->N >= 4096 && d->M % 256 == 0;
-    int fam = -100;
-    const bool p8_ok = d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && nseg == 1 && ng == 1 && d->N >= 256 && d->M >= 256;
-    // Default for well-filled bf16 launches: the 256x256 eight-phase kernel (gemm_p8.hip).  Measured at M = 12736 (bs 64) against the
-    // 128x128 kernels below: fc2 1105 vs 838 TFLOP/s, out-proj 760 vs 633, conv1 1084 vs 881, 4096^3 1248 vs 1058; a launch with fewer
-    // than ~0.7 tiles per CU (fc2 at M = 6368: 100 tiles) keeps the small-tile kernels.  OCC_GEMM_P8=0 switches it off.
-    if (fp8) {                                  // the eight-phase kernel is the fp8 path (any size: edge tiles are clamped / masked as for bf16)
-        OCC_CHECK_ARG((d->N * d->ldw) < (1ll << 32), "occ_gemm: fp8 W too large for 32-bit DMA offsets");
-        gemm_p8_launch(a, s, d->ab_dtype == OCC_FP8_E4M3 ? 1 : 2);
-        OCC_LAUNCH_CHECK("occ_gemm");
-        return OCC_OK;
-    }
-    static const int p8_env = getenv("OCC_GEMM_P8") ? atoi(getenv("OCC_GEMM_P8")) : 1;
-    const long long p8_tiles = occ_cdiv(d->M, 256) * occ_cdiv(d->N, 256);
-    const bool x_fits_32bit = true;            // DMA offsets are 32-bit byte offsets from the operand base (checked below)
-    if (p8_ok && (variant == 30 || (variant == 1 && p8_env && p8_tiles * 10 >= 7ll * cu_count())) && x_fits_32bit) {
-        // largest byte offset the kernel forms: last row of A through its row map, last row of W
-        const long long last_a = ((d->M - 1) / d->a_map.rows_per_batch) * d->a_map.batch_stride +
-                                 (d->a_map.rows_per_line > 0 ? (d->a_map.rows_per_batch / d->a_map.rows_per_line + 1) * d->a_map.line_stride + d->a_map.rows_per_line * d->a_map.row_stride
-                                                             : d->a_map.rows_per_batch * d->a_map.row_stride);
-        if ((last_a + d->K) * 2 < (1ll << 32) && (d->N * d->ldw) * 2 < (1ll << 32)) {
-            gemm_p8_launch(a, s);
-            OCC_LAUNCH_CHECK("occ_gemm");
-            return OCC_OK;
-        }
-    }
-    if (false) {
-        gemm_p8_launch(a, s);
-        OCC_LAUNCH_CHECK("occ_gemm");
-        return OCC_OK;
-    }
-    if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant != 1 && variant != 3 && variant != 4 && variant != 14 && variant != 19 && variant != 22) {
-        fam = gemm_family_launch(variant, a, d, ng, s);          // experimental kernels live in gemm_family.hip
-        if (fam != -100 && fam != OCC_OK) return fam;
-    }
-    if (fam == OCC_OK) {
-    } else if (d->ab_dtype == OCC_BF16 && d->K % 128 == 0 && variant == 22) {
+    if (d->ab_dtype == OCC_BF16 && d->K % 128 == 0 && variant == 22) {
         hipLaunchKernelGGL(gemm_bf16_ks2_kernel, dim3((unsigned)total, (unsigned)ng), dim3(512), 0, s, a);
-    } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 19) {
-        hipLaunchKernelGGL(gemm_bf16_dma2_kernel<false>, dim3((unsigned)total, (unsigned)ng), dim3(128), 0, s, a);
     } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 14) {
         hipLaunchKernelGGL(gemm_bf16_hs_kernel, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && (variant == 3 || (variant == 1 && big))) {
@@ -782,17 +643,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
             hipLaunchKernelGGL((gemm_bf16_dma_kernel<128, true>), dim3((unsigned)(total * a.ksplit), (unsigned)ng), dim3(THREADS), 0, s, a);
         } else
         {
-            // Experiment switch (OCC_GEMM_TILE_ROWS=112): 112-row tiles on the same 128-row LDS image, meant to spread M = 6368 more evenly
-            // over the CUs (out-proj: 400 tiles of 128 rows for 256 CUs).  Measured 5-15 % SLOWER than 128 rows on every front-end shape
-            // (out-proj 27.6 vs 25.5 us, fc1 83 vs 72 us), so it is never selected automatically.
-            static const int tile_rows_env = getenv("OCC_GEMM_TILE_ROWS") ? atoi(getenv("OCC_GEMM_TILE_ROWS")) : 0;
-            const bool use112 = tile_rows_env == 112;
-            if (use112) {
-                a.tile_rows = 112;
-                a.nbm = (int)occ_cdiv(d->M, 112);
-                hipLaunchKernelGGL((gemm_bf16_dma_kernel<128, false, 112>), dim3((unsigned)((long long)a.nbm * a.nbn), (unsigned)ng), dim3(THREADS), 0, s, a);
-            } else
-                hipLaunchKernelGGL(gemm_bf16_dma_kernel<128>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+            hipLaunchKernelGGL(gemm_bf16_dma_kernel<128>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
         }
     }
     else if (d->ab_dtype == OCC_BF16) hipLaunchKernelGGL(gemm_kernel<1>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);

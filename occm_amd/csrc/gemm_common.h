@@ -1,5 +1,5 @@
-// Shared pieces of the occ_gemm kernel family (gemm.hip: the product kernels and the occ_gemm entry point;
-// gemm_family.hip: the experimental kernels behind occ_gemm_variant): argument block, epilogues, LDS-DMA / fragment-read helpers.
+// Shared pieces of the occ_gemm kernel family (gemm.hip: the 128x128 kernels and the occ_gemm entry point; gemm_p8.hip: the 256x256
+// eight-phase kernel): argument block, epilogues, LDS-DMA / fragment-read helpers.
 #pragma once
 #include "occ_common.h"
 #include <stdlib.h>
@@ -30,7 +30,6 @@ struct GemmArgs {
     int ksplit;              // > 1: the K range is cut into ksplit pieces handled by different workgroups, C += alpha*acc with f32 atomics
     int slabs_per_split;
     int tile_rows;           // default 128x128 kernels: rows per output tile (multiple of 16, <= 128; the LDS image stays 128 rows) -- see occ_gemm
-    int dbg;                 // ablation bits (timing experiments only, results wrong): 1 no loads in the K loop, 2 no MFMA, 4 no fragment reads
 #ifdef P8_DIAG
     unsigned long long* diag;   // scripts/diag_p8.hip only: per workgroup {clock at entry, after the prologue, after the K loop, at exit, realtime entry, realtime exit}
 #endif
@@ -327,8 +326,5 @@ inline int cu_count() {
 
 // 256x256 eight-phase kernel (gemm_p8.hip); the caller has checked: bf16 operands, K % 64 == 0, one K segment, one group
 void gemm_p8_launch(GemmArgs& a, hipStream_t s, int fmt = 0);
-
-// experimental kernels (gemm_family.hip); returns -100 when `variant` is not one of them, else OCC_OK / an error status
-int gemm_family_launch(int variant, GemmArgs& a, const occ_gemm_desc* d, long long ng, hipStream_t s);
 
 }  // namespace occ_gemm_detail

@@ -8,8 +8,6 @@ from occm_amd._lib import lib
 
 variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,5").split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-if os.environ.get("GEMM_DBG"):
-    lib().occ_gemm_debug(int(os.environ["GEMM_DBG"]))
 shapes = [("fc1", 6368, 4096, 1024, True), ("fc2", 6368, 1024, 4096, False), ("qkv", 6368, 3072, 1024, False), ("out", 6368, 1024, 1024, False),
           ("conv1", 204768, 512, 1536, False), ("conv3", 51168, 512, 1536, False), ("conv5", 12768, 512, 1024, False), ("sq4k", 4096, 4096, 4096, False)]
 if os.environ.get("GEMM_SHAPES"):

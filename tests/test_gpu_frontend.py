@@ -197,9 +197,9 @@ def test_sslmodel_dropin_surface():
     assert m.out_dim == 256 and y.shape == (2, 12, 256) and torch.equal(y, y3)
 
 
-@pytest.mark.parametrize("variant", [3, 5, 6, 8, 9, 11, 12, 13, 14, 15, 16, 17, 19, 20, 22, 30])
+@pytest.mark.parametrize("variant", [3, 14, 22, 30])
 def test_bf16_gemm_kernel_family_agrees(variant):
-    """occ_gemm_variant selects other kernels of the bf16 family (256-wide tile, multi-stage LDS pipelines, persistent forms).
+    """occ_gemm_variant forces one kernel of the bf16 family (256x128 tile, half-slab pipeline, in-workgroup split-K, 256x256 eight-phase).
     They are tuning alternatives of the default and must give the same results on ragged tiles, conv windows and the grouped,
     K-segmented positional conv."""
     from occm_amd._lib import lib
