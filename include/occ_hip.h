@@ -145,6 +145,9 @@ int occ_fp8_update_scales(float* amax, float* scale, float* inv_scale, int64_t n
  * 256x256 eight-phase kernel; 3 = 256x128 LDS-DMA tile; 14 = half-slab pipeline; 22 = in-workgroup split-K); v < 0 only queries.
  * Returns the previous value.  Initialised from OCC_GEMM_VARIANT.  Results agree across kernels up to f32 summation order.  */
 int occ_gemm_variant(int v);
+/* Which kernel family the calling thread's last occ_gemm call launched (-1 before the first call): lets tests pin the dispatch. */
+enum { OCC_GEMM_KERNEL_OTHER = 0, OCC_GEMM_KERNEL_P8 = 8, OCC_GEMM_KERNEL_P8_FP8 = 9 };
+int occ_gemm_last_kernel(void);
 
 
 /* Weight-gradient GEMM (f32): C[n1,n2] += alpha * sum_m A[m,n1] * B[m,n2]; A rows [N1] and B rows [N2] go through

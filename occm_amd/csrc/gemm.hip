@@ -537,6 +537,10 @@ int g_variant = getenv("OCC_GEMM_VARIANT") ? atoi(getenv("OCC_GEMM_VARIANT")) : 
 
 using namespace occ_gemm_detail;
 
+thread_local int g_last_kernel = -1;          // OCC_GEMM_KERNEL_* of the calling thread's last occ_gemm launch
+
+extern "C" int occ_gemm_last_kernel(void) { return g_last_kernel; }
+
 extern "C" int occ_gemm_variant(int v) {
     const int prev = g_variant;
     if (v >= 0) g_variant = v;
@@ -596,6 +600,32 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     // 256x128 tiles only pay on large square problems (4096^3: 999 vs 865 TFLOP/s); on the front-end shapes (M = 6368, or N = 512)
     // the 128x128 tile's finer granularity wins by 3-15 % (scripts/bench_gemm.py), so it stays the default there.
     const bool big = d->M >= 4096 && d->N >= 4096 && d->M % 256 == 0;
+    // The 256x256 eight-phase kernel (gemm_p8.hip) forms 32-bit byte offsets from the operand bases: largest one it can form = last row
+    // of A through its row map / last row of W, plus one row of K.
+    const long long es = fp8 ? 1 : 2;
+    const long long last_a = ((d->M - 1) / d->a_map.rows_per_batch) * d->a_map.batch_stride +
+                             (d->a_map.rows_per_line > 0 ? (d->a_map.rows_per_batch / d->a_map.rows_per_line + 1) * d->a_map.line_stride + d->a_map.rows_per_line * d->a_map.row_stride
+                                                         : d->a_map.rows_per_batch * d->a_map.row_stride);
+    const bool p8_fits = (last_a + d->K) * es < (1ll << 32) && d->N * d->ldw * es < (1ll << 32);
+    if (fp8) {                                  // the only fp8 kernel (any size: edge tiles are clamped / masked as for bf16)
+        OCC_CHECK_ARG(p8_fits, "occ_gemm: fp8 operands too large for 32-bit DMA offsets");
+        g_last_kernel = OCC_GEMM_KERNEL_P8_FP8;
+        gemm_p8_launch(a, s, d->ab_dtype == OCC_FP8_E4M3 ? 1 : 2);
+        OCC_LAUNCH_CHECK("occ_gemm");
+        return OCC_OK;
+    }
+    // Default for well-filled bf16 launches.  Measured at M = 12736 (bs 64) against the 128x128 kernels below: fc2 1105 vs 838 TFLOP/s,
+    // out-proj 760 vs 633, conv1 1084 vs 881, 4096^3 1248 vs 1058; a launch with fewer than ~0.7 tiles per CU (fc2 at M = 6368: 100
+    // tiles) keeps the small-tile kernels.  OCC_GEMM_P8=0 switches it off; variant 30 forces it.
+    static const int p8_env = getenv("OCC_GEMM_P8") ? atoi(getenv("OCC_GEMM_P8")) : 1;
+    const bool p8_ok = d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && nseg == 1 && ng == 1 && d->N >= 256 && d->M >= 256 && p8_fits;
+    if (p8_ok && (variant == 30 || (variant == 1 && p8_env && nbm256 * occ_cdiv(d->N, 256) * 10 >= 7ll * cu_count()))) {
+        g_last_kernel = OCC_GEMM_KERNEL_P8;
+        gemm_p8_launch(a, s);
+        OCC_LAUNCH_CHECK("occ_gemm");
+        return OCC_OK;
+    }
+    g_last_kernel = OCC_GEMM_KERNEL_OTHER;
     if (d->ab_dtype == OCC_BF16 && d->K % 128 == 0 && variant == 22) {
         hipLaunchKernelGGL(gemm_bf16_ks2_kernel, dim3((unsigned)total, (unsigned)ng), dim3(512), 0, s, a);
     } else if (d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && variant == 14) {

@@ -64,8 +64,11 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
     __builtin_amdgcn_s_barrier();                                                                  \
     __builtin_amdgcn_sched_barrier(0);
 
+// (the empty asm with a memory clobber pins compiler-visible LDS loads -- the fp8 fragments -- below the barrier: a raw s_barrier
+// builtin carries no fence, and a fragment load hoisted above it reads a half-tile before the lagging wave row has retired its DMA)
 #define P8_END_PHASE()                                                                             \
     __builtin_amdgcn_s_barrier();                                                                  \
+    asm volatile("" ::: "memory");                                                                 \
     __builtin_amdgcn_sched_barrier(0);
 
 template <int FMT>
@@ -156,7 +159,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (wr == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }       // the lagging wave row
+    asm volatile("" ::: "memory");
+    if (wr == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }       // the lagging wave row
 
 #ifdef P8_DIAG
     const unsigned long long dg_t1 = __builtin_amdgcn_s_memtime();
@@ -164,7 +168,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
 #endif
     u32x4 w0[2][2], w1[2][2], x[4][2];         // bf16: [16-row block][k-step]
     i32x8 w0q[2], w1q[2], xq[4];               // fp8: [16-row block], 32 consecutive bytes of the row per lane
-    const int unit_scales = 0x7f7f7f7f;        // E8M0 block scales of 1.0 for both operands
+    // E8M0 block scales of 1.0 for both operands, set once through an asm statement: the compiler then keeps ONE register for it and
+    // cannot re-materialise a v_mov right in front of an asm MFMA (a VALU write -> MFMA operand hazard its recogniser does not see).
+    int unit_scales;
+    asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(unit_scales));
     // fp8 fragments are plain 32-byte LDS loads (the DMA is inline asm, so the compiler sees no pending LDS writes to wait for): byte
     // offset of this lane's block in row fr of a 16-row group
     const unsigned f8x = (unsigned)((wr * 64 + fr) * 128 + ((fq ^ ((fr >> 1) & 3)) << 5));

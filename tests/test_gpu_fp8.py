@@ -50,6 +50,8 @@ def test_fp8_gemm_exact_integer_products(M, N, K, a_fmt):
     ops.gemm_raw(M, N, K, xq.cuda(), ops.rowmap(M, 0, K), wq.cuda(), K, out, ops.rowmap(M, 0, N), ops.OCC_F32, a_fmt, bias=bias.cuda())
     ref = xv.double() @ wv.double().T + bias.double()
     assert torch.equal(out.cpu().double(), ref), float((out.cpu().double() - ref).abs().max())
+    from occm_amd._lib import lib
+    assert lib().occ_gemm_last_kernel() == 9               # OCC_GEMM_KERNEL_P8_FP8
 
 
 @pytest.mark.parametrize("a_fmt", [5, 6])

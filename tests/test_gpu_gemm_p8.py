@@ -30,6 +30,23 @@ def test_p8_exact_integer_products(M, N, K):
     out = torch.full((M, N), 7777.0, device="cuda")
     ops.gemm_raw(M, N, K, x.bfloat16().cuda(), ops.rowmap(M, 0, K), w.bfloat16().cuda(), K, out, ops.rowmap(M, 0, N), ops.OCC_F32, ops.OCC_BF16, bias=bias.cuda())
     assert torch.equal(out.cpu().double(), ref), (M, N, K, float((out.cpu().double() - ref).abs().max()))
+    from occm_amd._lib import lib
+    assert lib().occ_gemm_last_kernel() == 8               # OCC_GEMM_KERNEL_P8: the launch really went to the eight-phase kernel
+
+
+def test_default_dispatch_sends_well_filled_bf16_launches_to_p8():
+    """Heuristic dispatch (variant 1): the bs-64 encoder shapes go to the eight-phase kernel, an under-filled launch does not."""
+    from occm_amd import ops
+    from occm_amd._lib import lib
+    prev = lib().occ_gemm_variant(1)
+    try:
+        for (M, N, K), want in (((12736, 1024, 1024), 8), ((12736, 4096, 1024), 8), ((12736, 1024, 4096), 8), ((512, 512, 1024), 0)):
+            x = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16); w = torch.zeros(N, K, device="cuda", dtype=torch.bfloat16)
+            out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            ops.gemm_raw(M, N, K, x, ops.rowmap(M, 0, K), w, K, out, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16)
+            assert lib().occ_gemm_last_kernel() == want, (M, N, K)
+    finally:
+        lib().occ_gemm_variant(prev)
 
 
 def test_p8_conv_windows_and_padded_output_rows():
