@@ -146,7 +146,7 @@ int occ_fp8_update_scales(float* amax, float* scale, float* inv_scale, int64_t n
  * Returns the previous value.  Initialised from OCC_GEMM_VARIANT.  Results agree across kernels up to f32 summation order.  */
 int occ_gemm_variant(int v);
 /* Which kernel family the calling thread's last occ_gemm call launched (-1 before the first call): lets tests pin the dispatch. */
-enum { OCC_GEMM_KERNEL_OTHER = 0, OCC_GEMM_KERNEL_P8 = 8, OCC_GEMM_KERNEL_P8_FP8 = 9 };
+enum { OCC_GEMM_KERNEL_OTHER = 0, OCC_GEMM_KERNEL_P8 = 8, OCC_GEMM_KERNEL_P8_FP8 = 9, OCC_GEMM_KERNEL_P8_TAIL = 10 /* eight-phase kernel + a small-tile launch for the last partial round */ };
 int occ_gemm_last_kernel(void);
 
 

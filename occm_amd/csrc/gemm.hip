@@ -531,6 +531,15 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_hs_kernel(const GemmArgs a) 
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Rows [m1, M) of a row map as a map of their own: true (and the element offset of row m1) when moving the base pointer does it --
+// no line structure, and m1 either inside the first batch of a single-batch map or on a batch boundary.
+bool rows_rebase(const occ_rowmap& m, long long M, long long m1, long long* off) {
+    if (m.rows_per_line > 0 || m.rows_per_batch < 1) return false;
+    if (m.rows_per_batch >= M) { *off = m1 * m.row_stride; return true; }
+    if (m1 % m.rows_per_batch == 0) { *off = (m1 / m.rows_per_batch) * m.batch_stride; return true; }
+    return false;
+}
+
 int g_variant = getenv("OCC_GEMM_VARIANT") ? atoi(getenv("OCC_GEMM_VARIANT")) : 1;
 
 }  // namespace occ_gemm_detail
@@ -620,6 +629,30 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     static const int p8_env = getenv("OCC_GEMM_P8") ? atoi(getenv("OCC_GEMM_P8")) : 1;
     const bool p8_ok = d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && nseg == 1 && ng == 1 && d->N >= 256 && d->M >= 256 && p8_fits;
     if (p8_ok && (variant == 30 || (variant == 1 && p8_env && nbm256 * occ_cdiv(d->N, 256) * 10 >= 7ll * cu_count()))) {
+        // Tail split: one workgroup per CU means a launch takes ceil(tiles / CUs) tile times, so 800 tiles on 256 CUs (fc1 at bs 64)
+        // pay four rounds for 3.125 rounds of work.  When the last round would be at most half full, the eight-phase kernel gets
+        // the row tiles that fill whole rounds and the remaining rows go through the heuristic again (they land on the 128x128
+        // kernels, 4 workgroups per CU: a fraction of one tile time).  Needs rows that can be re-based by moving the pointers.
+        static const int tail_env = getenv("OCC_GEMM_TAIL") ? atoi(getenv("OCC_GEMM_TAIL")) : 1;
+        const long long nbn256 = occ_cdiv(d->N, 256), tiles = nbm256 * nbn256, cus = cu_count(), rem = tiles % cus;
+        long long oa = 0, oc = 0, orr = 0;
+        const long long nbm1 = (tiles - rem) / nbn256, m1 = nbm1 * 256;
+        if (variant == 1 && tail_env && tiles > cus && rem > 0 && rem * 2 <= cus && nbm1 >= 1 && nbm1 < nbm256 && rows_rebase(d->a_map, d->M, m1, &oa) &&
+            rows_rebase(d->c_map, d->M, m1, &oc) && (!d->R || rows_rebase(d->r_map, d->M, m1, &orr))) {
+            occ_gemm_desc tail = *d;
+            tail.M = d->M - m1;
+            tail.A = (const char*)d->A + oa * 2;
+            tail.C = (char*)d->C + oc * (d->c_dtype == OCC_BF16 ? 2 : 4);
+            if (d->R) tail.R = (const char*)d->R + orr * (d->r_dtype == OCC_BF16 ? 2 : 4);
+            if (d->aux) tail.aux = (char*)d->aux + oc * 2;
+            a.M = m1;
+            g_last_kernel = OCC_GEMM_KERNEL_P8;
+            gemm_p8_launch(a, s);
+            OCC_LAUNCH_CHECK("occ_gemm");
+            const int rc = occ_gemm(&tail, stream);        // at most half a round of 256-row tiles: never splits again
+            g_last_kernel = OCC_GEMM_KERNEL_P8_TAIL;
+            return rc;
+        }
         g_last_kernel = OCC_GEMM_KERNEL_P8;
         gemm_p8_launch(a, s);
         OCC_LAUNCH_CHECK("occ_gemm");

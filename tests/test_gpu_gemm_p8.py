@@ -40,13 +40,37 @@ def test_default_dispatch_sends_well_filled_bf16_launches_to_p8():
     from occm_amd._lib import lib
     prev = lib().occ_gemm_variant(1)
     try:
-        for (M, N, K), want in (((12736, 1024, 1024), 8), ((12736, 4096, 1024), 8), ((12736, 1024, 4096), 8), ((512, 512, 1024), 0)):
+        for (M, N, K), want in (((12736, 1024, 1024), 8), ((12736, 4096, 1024), 10), ((12736, 3072, 1024), 10), ((12736, 1024, 4096), 8), ((512, 512, 1024), 0)):
             x = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16); w = torch.zeros(N, K, device="cuda", dtype=torch.bfloat16)
             out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             ops.gemm_raw(M, N, K, x, ops.rowmap(M, 0, K), w, K, out, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16)
             assert lib().occ_gemm_last_kernel() == want, (M, N, K)
     finally:
         lib().occ_gemm_variant(prev)
+
+
+def test_tail_split_matches_single_launch_exactly():
+    """800 tiles on 256 CUs: the heuristic runs 48 row tiles in the eight-phase kernel and rows 12288.. through the small-tile kernels;
+    integer operands make both exact, so the result must equal the forced single launch bit for bit -- bf16 output with bias, GELU
+    and the saved pre-activation, and f32 output with an f32 residual in a padded buffer."""
+    from occm_amd import ops
+    from occm_amd._lib import lib
+    M, N, K = 12736, 4096, 1024
+    x, w, bias = _ints(M, K, 21, -2, 2).bfloat16().cuda(), _ints(N, K, 22, -2, 2).bfloat16().cuda(), _ints(1, N, 23)[0].cuda()
+    res = _ints(M, N + 8, 24).cuda()
+    outs = []
+    for variant in (30, 1):
+        lib().occ_gemm_variant(variant)
+        o16 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16); aux = torch.zeros_like(o16)
+        ops.gemm_raw(M, N, K, x, ops.rowmap(M, 0, K), w, K, o16, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16, bias=bias, act=ops.ACT_GELU, aux=aux, alpha=1.0 / 64)
+        k1 = lib().occ_gemm_last_kernel()
+        o32 = torch.zeros(M, N + 8, device="cuda")
+        ops.gemm_raw(M, N, K, x, ops.rowmap(M, 0, K), w, K, o32, ops.rowmap(M, 0, N + 8), ops.OCC_F32, ops.OCC_BF16, R=res, r_map=ops.rowmap(M, 0, N + 8), r_dtype=ops.OCC_F32)
+        assert (k1, lib().occ_gemm_last_kernel()) == ((8, 8) if variant == 30 else (10, 10))
+        outs.append((o16, aux, o32))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(outs[0][2][:, :N].abs().max()) > 100 and float(outs[0][2][:, N:].abs().max()) == 0
 
 
 def test_p8_conv_windows_and_padded_output_rows():
