@@ -142,11 +142,12 @@ int occ_fp8_amax(const void* src, int src_dtype, int64_t n, float* amax, void* s
 int occ_fp8_update_scales(float* amax, float* scale, float* inv_scale, int64_t n, float fmax, float margin, void* stream);
 
 /* Tuning hook: forces one kernel of the bf16 GEMM family instead of the size heuristic (1 = heuristic, the default; 30 = the
- * 256x256 eight-phase kernel; 3 = 256x128 LDS-DMA tile; 14 = half-slab pipeline; 22 = in-workgroup split-K); v < 0 only queries.
+ * 256x256 eight-phase kernel, 31 = its 224-row form; 3 = 256x128 LDS-DMA tile; 14 = half-slab pipeline; 22 = in-workgroup split-K); v < 0 only queries.
  * Returns the previous value.  Initialised from OCC_GEMM_VARIANT.  Results agree across kernels up to f32 summation order.  */
 int occ_gemm_variant(int v);
 /* Which kernel family the calling thread's last occ_gemm call launched (-1 before the first call): lets tests pin the dispatch. */
-enum { OCC_GEMM_KERNEL_OTHER = 0, OCC_GEMM_KERNEL_P8 = 8, OCC_GEMM_KERNEL_P8_FP8 = 9, OCC_GEMM_KERNEL_P8_TAIL = 10 /* eight-phase kernel + a small-tile launch for the last partial round */ };
+enum { OCC_GEMM_KERNEL_OTHER = 0, OCC_GEMM_KERNEL_P8 = 8, OCC_GEMM_KERNEL_P8_FP8 = 9, OCC_GEMM_KERNEL_P8_TAIL = 10 /* eight-phase kernel + a small-tile launch for the last partial round */,
+       OCC_GEMM_KERNEL_P8_224 = 11 /* eight-phase kernel on 224-row tiles */ };
 int occ_gemm_last_kernel(void);
 
 

@@ -628,17 +628,32 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     // tiles) keeps the small-tile kernels.  OCC_GEMM_P8=0 switches it off; variant 30 forces it.
     static const int p8_env = getenv("OCC_GEMM_P8") ? atoi(getenv("OCC_GEMM_P8")) : 1;
     const bool p8_ok = d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && nseg == 1 && ng == 1 && d->N >= 256 && d->M >= 256 && p8_fits;
-    if (p8_ok && (variant == 30 || (variant == 1 && p8_env && nbm256 * occ_cdiv(d->N, 256) * 10 >= 7ll * cu_count()))) {
-        // Tail split: one workgroup per CU means a launch takes ceil(tiles / CUs) tile times, so 800 tiles on 256 CUs (fc1 at bs 64)
-        // pay four rounds for 3.125 rounds of work.  When the last round would be at most half full, the eight-phase kernel gets
-        // the row tiles that fill whole rounds and the remaining rows go through the heuristic again (they land on the 128x128
-        // kernels, 4 workgroups per CU: a fraction of one tile time).  Needs rows that can be re-based by moving the pointers.
+    if (p8_ok && (variant == 30 || variant == 31 || (variant == 1 && p8_env && nbm256 * occ_cdiv(d->N, 256) * 10 >= 7ll * cu_count()))) {
+        // One workgroup per CU: a launch takes ceil(tiles / CUs) tile times, so 800 tiles of 256 rows on 256 CUs (fc1 at bs 64) pay four
+        // rounds for 3.125 rounds of work and 200 tiles (N = 1024) leave 56 CUs idle.  Three forms, costed in tile-row units:
+        //   whole   ceil(tiles256 / CUs) * 256
+        //   tail    when the last round would be at most half full: the row tiles that fill whole rounds go to the eight-phase kernel,
+        //           the remaining rows through this function again (they land on the 128x128 kernels, 4 workgroups per CU: about a
+        //           third of a tile time plus a launch: costed 200, measured 943 vs 890 TFLOP/s whole vs 978 for 224-row tiles at 12736 x 4096 x 1024).  Needs rows that can be re-based by moving the pointers.
+        //   224     57 instead of 50 row tiles at M = 12736: 228 / 684 / 912 workgroups, the same rounds of a tile that costs 7/8.
         static const int tail_env = getenv("OCC_GEMM_TAIL") ? atoi(getenv("OCC_GEMM_TAIL")) : 1;
+        static const int r224_env = getenv("OCC_GEMM_224") ? atoi(getenv("OCC_GEMM_224")) : 1;
         const long long nbn256 = occ_cdiv(d->N, 256), tiles = nbm256 * nbn256, cus = cu_count(), rem = tiles % cus;
         long long oa = 0, oc = 0, orr = 0;
         const long long nbm1 = (tiles - rem) / nbn256, m1 = nbm1 * 256;
-        if (variant == 1 && tail_env && tiles > cus && rem > 0 && rem * 2 <= cus && nbm1 >= 1 && nbm1 < nbm256 && rows_rebase(d->a_map, d->M, m1, &oa) &&
-            rows_rebase(d->c_map, d->M, m1, &oc) && (!d->R || rows_rebase(d->r_map, d->M, m1, &orr))) {
+        const bool can_tail = variant == 1 && tail_env && tiles > cus && rem > 0 && rem * 2 <= cus && nbm1 >= 1 && nbm1 < nbm256 &&
+                              rows_rebase(d->a_map, d->M, m1, &oa) && rows_rebase(d->c_map, d->M, m1, &oc) && (!d->R || rows_rebase(d->r_map, d->M, m1, &orr));
+        const bool can_224 = rows_epilogue_applies(a) && (variant == 31 || (variant == 1 && r224_env));
+        const long long cost_whole = occ_cdiv(tiles, cus) * 256, cost_tail = can_tail ? (tiles / cus) * 256 + 200 : (1ll << 40),
+                        cost_224 = can_224 ? occ_cdiv(occ_cdiv(d->M, 224) * nbn256, cus) * 224 : (1ll << 40);
+        if (variant == 31 || (cost_224 < cost_whole && cost_224 < cost_tail)) {
+            OCC_CHECK_ARG(can_224, "occ_gemm: the 224-row tile has no epilogue for this combination");
+            g_last_kernel = OCC_GEMM_KERNEL_P8_224;
+            gemm_p8_launch(a, s, 0, 224);
+            OCC_LAUNCH_CHECK("occ_gemm");
+            return OCC_OK;
+        }
+        if (cost_tail < cost_whole) {
             occ_gemm_desc tail = *d;
             tail.M = d->M - m1;
             tail.A = (const char*)d->A + oa * 2;
@@ -646,7 +661,6 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
             if (d->R) tail.R = (const char*)d->R + orr * (d->r_dtype == OCC_BF16 ? 2 : 4);
             if (d->aux) tail.aux = (char*)d->aux + oc * 2;
             a.M = m1;
-            g_last_kernel = OCC_GEMM_KERNEL_P8;
             gemm_p8_launch(a, s);
             OCC_LAUNCH_CHECK("occ_gemm");
             const int rc = occ_gemm(&tail, stream);        // at most half a round of 256-row tiles: never splits again

@@ -211,7 +211,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 // residual and C are all accessed as whole contiguous row segments (64 columns = 256 B f32 / 128 B bf16, four rows per instruction).
 // lds_wave: >= 8704 bytes private to the calling wave, 16-byte aligned, not in use by anything else.
 template <int NJ, bool HASB, bool GELU, bool HASR, bool CBF, int AUXM>
-__device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int lane, unsigned char* lds_wave) {
+__device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int lane, unsigned char* lds_wave, int rows) {
     static_assert(NJ % 2 == 0, "row epilogue works on pairs of 16-row blocks");
     constexpr int RS = 272;
     const int fr = lane & 15, fq = lane >> 4;
@@ -232,7 +232,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
         for (int k = 0; k < 8; ++k) {
             f32x4 v = *reinterpret_cast<const f32x4*>(lds_wave + (k * 4 + rr) * RS + cc * 16);
             const long long m = mrow0 + ch * 32 + k * 4 + rr;
-            if (m >= a.M || n >= a.N) continue;
+            if (m >= a.M || n >= a.N || ch * 32 + k * 4 + rr >= rows) continue;
             const long long coff = (plain_c ? m * a.cmap.rstride : row_off(a.cmap, m)) + n;
             v = v * al;
             if (HASB) v += bv;
@@ -263,19 +263,25 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
 
 // Dispatcher: the combinations the front-end launches (no side tensor or one of the two fine-tuning forms; activation none / GELU;
 // residual none / f32) take the row-layout epilogue, anything else the generic one.  ncol0 / the wave's columns must lie inside one
-// 64-column span (true for every kernel of this family: a wave owns 64 output columns).
+// 64-column span (true for every kernel of this family: a wave owns 64 output columns).  rows: only the first `rows` rows of the wave's
+// NJ * 16 are stored (the 224-row tile passes 112) -- honoured by the row-layout forms only, see rows_epilogue_applies.
+__host__ __device__ inline bool rows_epilogue_applies(const GemmArgs& a) {
+    if (a.R && a.r_dtype != OCC_F32) return false;
+    if (a.aux) return !a.R && a.c_dtype != OCC_F32 && ((a.act == OCC_ACT_GELU && a.bias) || (a.act == OCC_ACT_GELU_GRAD && !a.bias));
+    return a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU;
+}
 template <int NJ>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int lane, long long cshift,
-                                                   unsigned char* lds_wave) {
+                                                   unsigned char* lds_wave, int rows = NJ * 16) {
     const int fr = lane & 15, fq = lane >> 4;
     if (cshift == 0 && (!a.R || a.r_dtype == OCC_F32)) {
         if (a.aux && !a.R && a.c_dtype != OCC_F32) {
-            if (a.act == OCC_ACT_GELU && a.bias) { gemm_epilogue_rows_t<NJ, true, true, false, true, 1>(a, acc, mrow0, ncol0, lane, lds_wave); return; }
-            if (a.act == OCC_ACT_GELU_GRAD && !a.bias) { gemm_epilogue_rows_t<NJ, false, false, false, true, 2>(a, acc, mrow0, ncol0, lane, lds_wave); return; }
+            if (a.act == OCC_ACT_GELU && a.bias) { gemm_epilogue_rows_t<NJ, true, true, false, true, 1>(a, acc, mrow0, ncol0, lane, lds_wave, rows); return; }
+            if (a.act == OCC_ACT_GELU_GRAD && !a.bias) { gemm_epilogue_rows_t<NJ, false, false, false, true, 2>(a, acc, mrow0, ncol0, lane, lds_wave, rows); return; }
         }
         if (!a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU)) {
             const int key = (a.bias ? 8 : 0) | (a.act == OCC_ACT_GELU ? 4 : 0) | (a.R ? 2 : 0) | (a.c_dtype != OCC_F32 ? 1 : 0);
-#define OCC_EPR(K, B, G, R, C) case K: gemm_epilogue_rows_t<NJ, B, G, R, C, 0>(a, acc, mrow0, ncol0, lane, lds_wave); break;
+#define OCC_EPR(K, B, G, R, C) case K: gemm_epilogue_rows_t<NJ, B, G, R, C, 0>(a, acc, mrow0, ncol0, lane, lds_wave, rows); break;
             switch (key) {
                 OCC_EPR(0, false, false, false, false) OCC_EPR(1, false, false, false, true) OCC_EPR(2, false, false, true, false) OCC_EPR(3, false, false, true, true)
                 OCC_EPR(4, false, true, false, false) OCC_EPR(5, false, true, false, true) OCC_EPR(6, false, true, true, false) OCC_EPR(7, false, true, true, true)
@@ -325,6 +331,6 @@ inline int cu_count() {
 
 
 // 256x256 eight-phase kernel (gemm_p8.hip); the caller has checked: bf16 operands, K % 64 == 0, one K segment, one group
-void gemm_p8_launch(GemmArgs& a, hipStream_t s, int fmt = 0);
+void gemm_p8_launch(GemmArgs& a, hipStream_t s, int fmt = 0, int tile_rows = 256);      // tile_rows 224: only with rows_epilogue_applies(a)
 
 }  // namespace occ_gemm_detail

@@ -37,7 +37,7 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #define P8_QUAD(NH, MH, WQ)                                                                        \
     __builtin_amdgcn_s_setprio(1);                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                               \
-        _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                           \
+        _Pragma("unroll") for (int mf = 0; mf < ((MH) ? MB - 4 : 4); ++mf)                         \
             _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                       \
                 P8_MFMA(acc[(NH) * 2 + nf][(MH) * 4 + mf], WQ[nf][ks], x[mf][ks]);                 \
     __builtin_amdgcn_s_setprio(0);                                                                 \
@@ -50,7 +50,7 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
     asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] blgp:" #XT : "+v"(ACC) : "v"(WF), "v"(XF), "v"(unit_scales));
 #define P8_QUAD_F8(NH, MH, WQ, XT)                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                 \
-    _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                               \
+    _Pragma("unroll") for (int mf = 0; mf < ((MH) ? MB - 4 : 4); ++mf)                             \
         _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                           \
             P8_MFMA_F8(acc[(NH) * 2 + nf][(MH) * 4 + mf], WQ[nf], xq[mf], XT)                      \
     __builtin_amdgcn_s_setprio(0);                                                                 \
@@ -71,8 +71,13 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
     asm volatile("" ::: "memory");                                                                 \
     __builtin_amdgcn_sched_barrier(0);
 
-template <int FMT>
+// MB: 16-row blocks per wave, 8 (256-row tiles) or 7 (224-row tiles: the LDS image keeps its 128-row slots per wave row, the last block
+// of the second m-half is neither multiplied nor stored).  M = 12736 (bs 64) is 49.75 tiles of 256 rows: with N = 1024 that is 200
+// workgroups for 256 CUs, and 600 / 800 for N = 3072 / 4096 -- 57 tiles of 224 rows make it 228 / 684 / 912, the same number of rounds
+// of a tile that costs 7/8.
+template <int FMT, int MB = 8>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
+    static_assert(MB == 8 || MB == 7, "8 or 7 blocks of 16 rows per wave");
     constexpr int ES = FMT == 0 ? 2 : 1;           // bytes per operand element; a K-tile is 128 bytes of every row
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 65536];
     const int total = a.nbm * a.nbn;
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
         tile_m = first_m + loc % gsz;
         tile_n = loc / gsz;
     }
-    const long long m0 = (long long)tile_m * 256, n0 = (long long)tile_n * 256;
+    const long long m0 = (long long)tile_m * (MB * 32), n0 = (long long)tile_n * 256;
 #ifdef P8_DIAG
     const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            long long m = m0 + q * 128 + h * 64 + wave * 8 + srow; if (m > a.M - 1) m = a.M - 1;
+            long long m = m0 + q * (MB * 16) + h * 64 + wave * 8 + srow; if (m > a.M - 1) m = a.M - 1;
             soff[h][q] = (unsigned)(row_off(a.xmap, m) * ES + sch * 16);
             long long n = n0 + (q * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + srow; if (n > a.N - 1) n = a.N - 1;
             soff[2 + h][q] = (unsigned)(n * a.ldw * ES + sch * 16);
@@ -213,11 +218,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 x[0][ks] = ds_read128<16384>(xa[B][ks]); x[1][ks] = ds_read128<16384 + 2048>(xa[B][ks]);
-                x[2][ks] = ds_read128<16384 + 4096>(xa[B][ks]); x[3][ks] = ds_read128<16384 + 6144>(xa[B][ks]);
+                x[2][ks] = ds_read128<16384 + 4096>(xa[B][ks]);
+                if constexpr (MB == 8) x[3][ks] = ds_read128<16384 + 6144>(xa[B][ks]);
             }
         } else {
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf) xq[mf] = P8_LD8(B * 65536 + f8x + 16384 + mf * 2048);
+            for (int mf = 0; mf < MB - 4; ++mf) xq[mf] = P8_LD8(B * 65536 + f8x + 16384 + mf * 2048);
         }
         if (t + 2 < nt) P8_STAGE(0, B, t + 2)
         P8_SYNC_READS()
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
     const unsigned long long dg_t2 = __builtin_amdgcn_s_memtime();
 #endif
     // all LDS is free here: no DMA is outstanding (the last phase waited vmcnt(0)) and every wave has finished its fragment reads
-    gemm_epilogue_rows<8>(a, acc, m0 + wr * 128, n0 + wc * 64, lane, 0, lds + wave * 16384);
+    gemm_epilogue_rows<8>(a, acc, m0 + wr * (MB * 16), n0 + wc * 64, lane, 0, lds + wave * 16384, MB * 16);
 #ifdef P8_DIAG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
@@ -261,11 +267,17 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
 
 // Launch helper used by occ_gemm.  Preconditions (checked by the caller): bf16 operands and K % 64 == 0, or fp8 operands (fmt 1: A e4m3,
 // fmt 2: A e5m2; W e4m3) and K % 128 == 0; one K segment, one group.
-void gemm_p8_launch(GemmArgs& a, hipStream_t s, int fmt) {
-    a.nbm = (int)occ_cdiv(a.M, 256);
+void gemm_p8_launch(GemmArgs& a, hipStream_t s, int fmt, int tile_rows) {
+    a.nbm = (int)occ_cdiv(a.M, tile_rows);
     a.nbn = (int)occ_cdiv(a.N, 256);
     a.group_m = a.nbm >= 8 ? 8 : 0;
     const dim3 grid((unsigned)((long long)a.nbm * a.nbn));
+    if (tile_rows == 224) {
+        if (fmt == 0) hipLaunchKernelGGL((gemm_p8_kernel<0, 7>), grid, dim3(512), 0, s, a);
+        else if (fmt == 1) hipLaunchKernelGGL((gemm_p8_kernel<1, 7>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((gemm_p8_kernel<2, 7>), grid, dim3(512), 0, s, a);
+        return;
+    }
     if (fmt == 0) hipLaunchKernelGGL(gemm_p8_kernel<0>, grid, dim3(512), 0, s, a);
     else if (fmt == 1) hipLaunchKernelGGL(gemm_p8_kernel<1>, grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL(gemm_p8_kernel<2>, grid, dim3(512), 0, s, a);

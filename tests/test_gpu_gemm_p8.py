@@ -40,7 +40,7 @@ def test_default_dispatch_sends_well_filled_bf16_launches_to_p8():
     from occm_amd._lib import lib
     prev = lib().occ_gemm_variant(1)
     try:
-        for (M, N, K), want in (((12736, 1024, 1024), 8), ((12736, 4096, 1024), 10), ((12736, 3072, 1024), 10), ((12736, 1024, 4096), 8), ((512, 512, 1024), 0)):
+        for (M, N, K), want in (((12736, 1024, 1024), 11), ((12736, 4096, 1024), 11), ((12736, 3072, 1024), 11), ((12736, 1024, 4096), 11), ((4096, 4096, 4096), 8), ((512, 512, 1024), 0)):
             x = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16); w = torch.zeros(N, K, device="cuda", dtype=torch.bfloat16)
             out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             ops.gemm_raw(M, N, K, x, ops.rowmap(M, 0, K), w, K, out, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16)
@@ -49,15 +49,39 @@ def test_default_dispatch_sends_well_filled_bf16_launches_to_p8():
         lib().occ_gemm_variant(prev)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (448, 256, 128), (1000, 512, 1024), (12736, 1024, 1024), (2049, 260, 448)])
+def test_p8_224_row_tiles_exact(M, N, K):
+    """Variant 31: seven 16-row blocks per wave.  Exact integer products, rows past a wave's 112 untouched (the output buffer is
+    pre-filled and compared whole), bf16 output with GELU + saved pre-activation against the 256-row kernel bit for bit."""
+    from occm_amd import ops
+    from occm_amd._lib import lib
+    x, w = _ints(M, K, 1), _ints(N, K, 2)
+    bias = _ints(1, N, 3)[0]
+    ref = x.double() @ w.double().T + bias.double()
+    xb, wb = x.bfloat16().cuda(), w.bfloat16().cuda()
+    res = []
+    for variant in (31, 30):
+        lib().occ_gemm_variant(variant)
+        out = torch.full((M, N), 7777.0, device="cuda")
+        ops.gemm_raw(M, N, K, xb, ops.rowmap(M, 0, K), wb, K, out, ops.rowmap(M, 0, N), ops.OCC_F32, ops.OCC_BF16, bias=bias.cuda())
+        assert lib().occ_gemm_last_kernel() == (11 if variant == 31 else 8)
+        assert torch.equal(out.cpu().double(), ref), (variant, float((out.cpu().double() - ref).abs().max()))
+        o16 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16); aux = torch.zeros_like(o16)
+        ops.gemm_raw(M, N, K, xb, ops.rowmap(M, 0, K), wb, K, o16, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16, bias=bias.cuda(), act=ops.ACT_GELU, aux=aux, alpha=1.0 / 64)
+        res.append((o16, aux))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_tail_split_matches_single_launch_exactly():
-    """800 tiles on 256 CUs: the heuristic runs 48 row tiles in the eight-phase kernel and rows 12288.. through the small-tile kernels;
-    integer operands make both exact, so the result must equal the forced single launch bit for bit -- bf16 output with bias, GELU
-    and the saved pre-activation, and f32 output with an f32 residual in a padded buffer."""
+    """800 tiles on 256 CUs.  With a row-layout epilogue the heuristic takes 224-row tiles; without one (bf16 residual) it runs 48 row
+    tiles in the eight-phase kernel and rows 12288.. through the small-tile kernels.  Integer operands make every form exact, so the
+    results must equal the forced single launch bit for bit -- bf16 output with bias, GELU and the saved pre-activation, and f32
+    output with a bf16 residual in a padded buffer."""
     from occm_amd import ops
     from occm_amd._lib import lib
     M, N, K = 12736, 4096, 1024
     x, w, bias = _ints(M, K, 21, -2, 2).bfloat16().cuda(), _ints(N, K, 22, -2, 2).bfloat16().cuda(), _ints(1, N, 23)[0].cuda()
-    res = _ints(M, N + 8, 24).cuda()
+    res = _ints(M, N + 8, 24).bfloat16().cuda()
     outs = []
     for variant in (30, 1):
         lib().occ_gemm_variant(variant)
@@ -65,8 +89,8 @@ def test_tail_split_matches_single_launch_exactly():
         ops.gemm_raw(M, N, K, x, ops.rowmap(M, 0, K), w, K, o16, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16, bias=bias, act=ops.ACT_GELU, aux=aux, alpha=1.0 / 64)
         k1 = lib().occ_gemm_last_kernel()
         o32 = torch.zeros(M, N + 8, device="cuda")
-        ops.gemm_raw(M, N, K, x, ops.rowmap(M, 0, K), w, K, o32, ops.rowmap(M, 0, N + 8), ops.OCC_F32, ops.OCC_BF16, R=res, r_map=ops.rowmap(M, 0, N + 8), r_dtype=ops.OCC_F32)
-        assert (k1, lib().occ_gemm_last_kernel()) == ((8, 8) if variant == 30 else (10, 10))
+        ops.gemm_raw(M, N, K, x, ops.rowmap(M, 0, K), w, K, o32, ops.rowmap(M, 0, N + 8), ops.OCC_F32, ops.OCC_BF16, R=res, r_map=ops.rowmap(M, 0, N + 8), r_dtype=ops.OCC_BF16)
+        assert (k1, lib().occ_gemm_last_kernel()) == ((8, 8) if variant == 30 else (11, 10))
         outs.append((o16, aux, o32))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
