@@ -291,6 +291,22 @@ int occ_add_batch_vec(float* x, const occ_rowmap* x_map, const float* v, int64_t
  * to 4, as the forward implicit GEMM uses it) -> dx [B,H,W]; needed only when the front-end under the SE-ResNet is fine-tuned.            */
 int occ_conv7s2_dgrad_c1(const float* dy, const float* w, float* dx, int64_t B, int64_t H, int64_t W, void* stream);
 
+/* ---------------------------------------------------- LCNN back-end pieces (models/lcnn.py:121-241), f32 channels-last ---- */
+/* Max-Feature-Map (mfm.forward, lcnn.py:133-136): y[r, c] = max(x[r, c], x[r, C + c]), x rows of 2C contiguous floats, y rows through y_map.
+ * bwd: torch.maximum's derivative -- the larger half takes dy, a tie splits it evenly; dx [rows, 2C] is written completely.            */
+int occ_mfm_fwd(const float* x, float* y, const occ_rowmap* y_map, int64_t rows, int64_t C, void* stream);
+int occ_mfm_bwd(const float* dy, const occ_rowmap* dy_map, const float* x, float* dx, int64_t rows, int64_t C, void* stream);
+/* MFM followed by nn.MaxPool2d(2, 2) (lcnn.py:154-166) in one pass: x [B,H,W,2C] -> y [B,H/2,W/2,C] (rows through y_map), idx u8
+ * [B,H/2,W/2,C] = winning window slot | winning half << 2; bwd writes all of dx [B,H,W,2C] (rows of 2C floats through dx_map, e.g. the
+ * interior of the zero-bordered buffer the input-gradient correlation reads).                                                         */
+int occ_mfm_pool2_fwd(const float* x, float* y, const occ_rowmap* y_map, uint8_t* idx, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+int occ_mfm_pool2_bwd(const float* dy, const occ_rowmap* dy_map, const uint8_t* idx, float* dx, const occ_rowmap* dx_map, int64_t B, int64_t H, int64_t W, int64_t C,
+                      void* stream);
+/* nn.AdaptiveAvgPool2d((1, Wout)) + flatten (lcnn.py:169, 191-194): x [B,H,W,C] -> out [B, C*Wout] with out[b, c*Wout + i] = mean over
+ * all rows and torch's adaptive column bin i.                                                                                         */
+int occ_adaptive_avgpool_1xw_fwd(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t Wout, void* stream);
+int occ_adaptive_avgpool_1xw_bwd(const float* dout, float* dx, int64_t B, int64_t H, int64_t W, int64_t C, int64_t Wout, void* stream);
+
 /* ------------------------------------------------------------- front-end row kernels ------- */
 /* y = LayerNorm(x) * gamma + beta, optional GELU, over rows of width C (C % 64 == 0, C <= 8192).
  * fairseq LayerNorm / Fp32LayerNorm + GELU of the conv blocks and transformer layers.            */

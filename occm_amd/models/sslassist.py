@@ -228,6 +228,10 @@ class AasistBackend:
                 ws["D1_%d" % i] = z(B, 43, Wp, co)            # grad wrt conv1 output
                 ws["D%d" % i] = z(B, 44, Wp, co)              # grad wrt block output
             self._ws[key] = ws
+            while len(self._ws) > 12:                  # variable-length scoring: keep the most recent shapes only
+                self._ws.pop(next(iter(self._ws)))
+        else:
+            self._ws[key] = self._ws.pop(key)
         return self._ws[key]
 
     # ---------------------------------------------------------------------------------- helpers --

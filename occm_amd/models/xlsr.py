@@ -18,6 +18,7 @@ from .. import ops
 from .._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, OCC_AF32_WBF16, OCC_BF16 as OCC_BF16_CODE, OCC_F32, OccError, dtype_code, require_gpu
 from ..ops import rowmap
 
+WS_CACHE = 12            # activation workspaces kept per model (one per distinct input shape)
 CONV_LAYERS = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2     # fairseq conv_feature_layers of XLS-R
 
 
@@ -141,6 +142,10 @@ class XlsrFrontend:
             ws["att"] = torch.empty(M, cfg.dim, device=dev, dtype=dt)
             ws["ffn"] = torch.empty(M, cfg.ffn, device=dev, dtype=dt)
             self._ws[key] = ws
+            while len(self._ws) > WS_CACHE:            # variable-length scoring meets thousands of (B, L): keep the most recent shapes only
+                self._ws.pop(next(iter(self._ws)))
+        else:
+            self._ws[key] = self._ws.pop(key)          # most recently used last
         return self._ws[key]
 
     def forward(self, wav, out_dtype=None, taps=None, slot=0, out=None):

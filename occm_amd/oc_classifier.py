@@ -47,19 +47,66 @@ class ASVDataset(Dataset):
         return torch.tensor(feature, dtype=torch.float32), torch.tensor(label, dtype=torch.int64)
 
 
-def create_reference_embedding2(model, dataloader, device, cache=True):
+def n_frames(L):
+    """Frames the wav2vec2 conv stack makes of L samples (kernels 10,3,3,3,3,2,2; strides 5,2,2,2,2,2,2)."""
+    for k, s in ((10, 5), (3, 2), (3, 2), (3, 2), (3, 2), (2, 2), (2, 2)):
+        L = (L - k) // s + 1
+    return L
+
+
+def canonical_len(T):
+    """Samples that T frames depend on: receptive field 400, hop 320.  The conv stack has no padding, so samples past this point
+    complete no further frame and change nothing: cropping an utterance to canonical_len(n_frames(L)) leaves its features unchanged."""
+    return (T - 1) * 320 + 400
+
+
+def embed_dataset(model, dataloader, device, batch_size=1):
+    """(emb [N,160], logits [N,2]) of every utterance, in dataset order.
+
+    batch_size 1 is the reference's loop (oc_classifier.py:182-186, 243-265: one utterance per forward).  batch_size > 1 buckets by
+    frame count: utterances with the same number of frames, cropped to that count's canonical length, form one batch, so no padding
+    enters any layer and no key mask is needed -- per-utterance results differ from the one-at-a-time loop only through the GEMM
+    kernels picked for a different row count (summation order).  Buckets fill as the loader delivers utterances; at most
+    (#distinct frame counts in flight) x batch_size waveforms are held."""
+    model.eval()
+    n = len(dataloader.dataset)
+    embs, logits = torch.empty(n, 160, device=device), torch.empty(n, 2, device=device)
+    pending = {}
+
+    def flush(items):
+        idxs = torch.tensor([i for i, _ in items], device=device)
+        emb, out = model(torch.stack([w for _, w in items]).to(device))
+        embs[idxs] = emb.float(); logits[idxs] = out.float()
+
+    pos = 0
+    with torch.no_grad():
+        for data, _ in dataloader:
+            for row in data:                                   # the loader may itself deliver more than one utterance
+                if batch_size <= 1:
+                    flush([(pos, row)])
+                else:
+                    T = n_frames(row.numel())
+                    if T < 1:
+                        raise ValueError("utterance %d: %d samples are too short for the conv stack" % (pos, row.numel()))
+                    bucket = pending.setdefault(T, [])
+                    bucket.append((pos, row[:canonical_len(T)]))
+                    if len(bucket) == batch_size:
+                        flush(pending.pop(T))
+                pos += 1
+        for T in sorted(pending):
+            flush(pending[T])
+    if pos != n:
+        raise RuntimeError("loader delivered %d of %d utterances" % (pos, n))
+    return embs, logits
+
+
+def create_reference_embedding2(model, dataloader, device, cache=True, batch_size=1):
     """oc_classifier.py:159-202: mean embedding of the bona-fide set, threshold = largest distance to it."""
     if cache and os.path.exists("reference_embedding.pt") and os.path.exists("threshold.pt"):
         print("Loading reference embedding and threshold...")
         return torch.load("reference_embedding.pt"), torch.load("threshold.pt")
     print("Creating a reference embedding...")
-    model.eval()
-    embs = []
-    with torch.no_grad():
-        for data, _ in dataloader:
-            emb, _ = model(data.to(device))
-            embs.append(emb.clone())
-    embs = torch.cat(embs, dim=0)                                   # [N,160]
+    embs, _ = embed_dataset(model, dataloader, device, batch_size)      # [N,160]
     reference_embedding = embs.mean(dim=0, keepdim=True)            # [1,160] like torch.mean(torch.stack(..), 0)
     dist = ops.pairwise_dist(reference_embedding.reshape(-1).contiguous(), embs.contiguous())
     with open("distances.txt", "a") as f:
@@ -72,25 +119,23 @@ def create_reference_embedding2(model, dataloader, device, cache=True):
     return reference_embedding, threshold
 
 
-def score_eval_set_1c2(model, dataloader, device, reference_embedding, threshold, path="scores.txt"):
+def score_eval_set_1c2(model, dataloader, device, reference_embedding, threshold, path="scores.txt", batch_size=1):
     """One-class scoring (oc_classifier.py:243-265): distance to the reference embedding, 1 when above the threshold."""
-    model.eval()
     thr = float(threshold)
     print("Scoring the evaluation set...")
-    with open(path, "w") as f, torch.no_grad():
-        for idx, (data, _) in enumerate(dataloader):
-            emb, _ = model(data.to(device))
-            d = float(ops.pairwise_dist(reference_embedding.reshape(-1).contiguous(), emb.contiguous())[0])
+    embs, _ = embed_dataset(model, dataloader, device, batch_size)
+    dist = ops.pairwise_dist(reference_embedding.reshape(-1).contiguous(), embs.contiguous()).tolist()
+    with open(path, "w") as f:
+        for d in dist:
             f.write(f"{d}, 1 \n" if d > thr else f"{d}, 0 \n")
 
 
-def score_eval_set_2c2(model, dataloader, device, path="scores.txt"):
+def score_eval_set_2c2(model, dataloader, device, path="scores.txt", batch_size=1):
     """Two-class scoring (oc_classifier.py:292-312): the bona-fide logit."""
-    model.eval()
-    with open(path, "w") as f, torch.no_grad():
-        for data, _ in dataloader:
-            _, out = model(data.to(device))
-            f.write(f"{float(out[0][0])}\n")
+    _, logits = embed_dataset(model, dataloader, device, batch_size)
+    with open(path, "w") as f:
+        for v in logits[:, 0].tolist():
+            f.write(f"{v}\n")
 
 
 def main(argv=None):
@@ -103,6 +148,8 @@ def main(argv=None):
     parser.add_argument("--eval_protocol_file", type=str, default="/datab/Dataset/ASVspoof/LA/ASVspoof_LA_cm_protocols/ASVspoof2019.LA.cm.eval.trl.txt")
     parser.add_argument("--eval_dataset_dir", type=str, default="/datab/Dataset/ASVspoof/LA/ASVspoof2019_LA_eval/flac")
     parser.add_argument("--two_class", action="store_true", help="score with the bona-fide logit (score_eval_set_2c2)")
+    parser.add_argument("--batch_size", type=int, default=1, help="1 = the reference's one-utterance loop; > 1 = batches of utterances with equal frame count")
+    parser.add_argument("--num_workers", type=int, default=0)
     args = parser.parse_args(argv)
     from .models.sslassist import AModel
     device = torch.device("cuda")
@@ -114,13 +161,13 @@ def main(argv=None):
     aasist = AModel(None, device, ssl_state_dict=ssl)
     aasist.load_state_dict(sd, strict=True)
     print("Pretrained weights loaded")
-    train_loader = DataLoader(ASVDataset(args.protocol_file, args.dataset_dir), batch_size=1, shuffle=False, num_workers=0)
-    reference_embedding, threshold = create_reference_embedding2(aasist, train_loader, device)
-    eval_loader = DataLoader(ASVDataset(args.eval_protocol_file, args.eval_dataset_dir, eval=True), batch_size=1, shuffle=False, num_workers=0)
+    train_loader = DataLoader(ASVDataset(args.protocol_file, args.dataset_dir), batch_size=1, shuffle=False, num_workers=args.num_workers)
+    reference_embedding, threshold = create_reference_embedding2(aasist, train_loader, device, batch_size=args.batch_size)
+    eval_loader = DataLoader(ASVDataset(args.eval_protocol_file, args.eval_dataset_dir, eval=True), batch_size=1, shuffle=False, num_workers=args.num_workers)
     if args.two_class:
-        score_eval_set_2c2(aasist, eval_loader, device)
+        score_eval_set_2c2(aasist, eval_loader, device, batch_size=args.batch_size)
     else:
-        score_eval_set_1c2(aasist, eval_loader, device, reference_embedding, threshold)
+        score_eval_set_1c2(aasist, eval_loader, device, reference_embedding, threshold, batch_size=args.batch_size)
     print(f"threshold = {threshold}")
 
 

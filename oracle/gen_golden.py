@@ -22,7 +22,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
-from oracle import aasist_ref, senet_ref            # noqa: E402  (shape tables only)
+from oracle import aasist_ref, lcnn_ref, senet_ref  # noqa: E402  (shape tables only)
 from oracle.fill import fill_like                    # noqa: E402
 
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
@@ -239,6 +239,47 @@ def gen_senet():
     print("senet.npz", len(out))
 
 
+def gen_lcnn():
+    """models/lcnn.py ``lcnn_net(asoftmax=False)`` (the form occm.py:52 and lcnn.py:244 build): eval outputs, and a train-mode pass with
+    the Dropout probabilities forced to 0 (module attribute, not a source change): outputs, BatchNorm running statistics afterwards, every
+    parameter-gradient norm and three whole gradients of sum(logits * fixed weights)."""
+    _stub("fairseq")
+    sys.path.insert(0, os.path.join(REF, "models"))
+    xl = types.ModuleType("xlsr"); xl.SSLModel = object; sys.modules["xlsr"] = xl
+    lc = _load("ref_lcnn", os.path.join(REF, "models", "lcnn.py"))
+    m = lc.lcnn_net(asoftmax=False)
+    params = fill_like(lcnn_ref.param_shapes(), seed=4)
+    m.load_state_dict(params, strict=True)              # proves the key/shape table equals the reference's
+    out = {}
+    for tag, shp, s in (("a", (3, 1, 48, 1024), 21), ("b", (2, 1, 199, 1024), 22)):
+        g = torch.Generator().manual_seed(s)
+        x = torch.randn(*shp, generator=g)
+        m.load_state_dict(params, strict=True)
+        m.eval()
+        with torch.no_grad():
+            out["eval_" + tag] = m(x).numpy()
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        m.zero_grad()
+        y = m(x)
+        wgt = torch.randn(y.shape, generator=g)
+        (y * wgt).sum().backward()
+        out["train_" + tag] = y.detach().numpy(); out["train_wgt_" + tag] = wgt.numpy()
+        sd = m.state_dict()
+        for k in ("layer2.2.running_mean", "layer2.2.running_var", "layer3.2.running_mean", "layer3.2.running_var"):
+            out["rs_%s_%s" % (tag, k)] = sd[k].numpy().copy()
+        names, norms = [], []
+        for k, v in m.named_parameters():
+            names.append(k); norms.append(float(v.grad.norm()) if v.grad is not None else -1.0)
+        out["gradnames_" + tag] = np.array(names); out["gradnorms_" + tag] = np.array(norms)
+        for k in ("layer1.0.filter.weight", "layer3.0.conv.filter.weight", "fc0.0.filter.0.weight"):
+            out["grad_%s_%s" % (tag, k)] = dict(m.named_parameters())[k].grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "lcnn.npz"), **out)
+    print("lcnn.npz", len(out))
+
+
 def gen_protocol():
     _stub("librosa")
     du = sys.modules.get("ref_data_utils_SSL") or _load("ref_data_utils_SSL", os.path.join(REF, "data_utils_SSL.py"))
@@ -261,4 +302,5 @@ if __name__ == "__main__":
     gen_aasist()
     gen_train_steps()
     gen_senet()
+    gen_lcnn()
     gen_protocol()

@@ -82,6 +82,48 @@ def test_reference_embedding_threshold_and_scores_match_oracle(tmp_path, monkeyp
         assert int(flag) == int(float(dist) > float(thr))
 
 
+def test_bucketed_batch_scoring_equals_one_at_a_time(tmp_path, monkeypatch):
+    """--batch_size 3: utterances are grouped by frame count and cropped to the samples those frames depend on; scores.txt, the reference
+    embedding and the threshold must equal the reference's one-utterance loop (f32 front-end: to 2e-4; the two differ only in the GEMM
+    kernel picked for a different row count), in dataset order, with ragged lengths, a bucket that never fills and repeated frame counts."""
+    from oracle import aasist_ref, xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.models import xlsr
+    from occm_amd.models.sslassist import AModel
+    from occm_amd.oc_classifier import ASVDataset, canonical_len, create_reference_embedding2, embed_dataset, n_frames, score_eval_set_1c2
+    from torch.utils.data import DataLoader
+    monkeypatch.chdir(tmp_path)
+    d = tmp_path / "audio"; d.mkdir()
+    lens = [9000, 8720, 9039, 12000, 8800, 12100, 8900, 15000, 8999, 12239, 8721]           # frame counts 27 x7 (two full buckets + 1), 37 x3, 46 x1
+    assert sorted(set(n_frames(L) for L in lens)) == [27, 37, 46] and canonical_len(27) == 8720
+    lines = []
+    for i, L in enumerate(lens):
+        _write_wav(str(d / f"U{i}.wav"), L, 100 + i)
+        lines.append(f"LA_{i} U{i} - - bonafide")
+    (tmp_path / "train.txt").write_text("\n".join(lines) + "\n")
+    (tmp_path / "eval.txt").write_text("\n".join(f"U{i}" for i in range(len(lens))) + "\n")
+    kw = dict(dim=1024, ffn=512, heads=16, layers=1)
+    rcfg, cfg = xlsr_ref.XlsrConfig(**kw), xlsr.XlsrConfig(**kw)
+    model = AModel(None, "cuda", ssl_cfg=cfg, ssl_dtype=torch.float32, ssl_state_dict=fill_like(xlsr_ref.param_shapes(rcfg), seed=3),
+                   backend_state_dict=fill_like(aasist_ref.param_shapes(), seed=0))
+    tr = DataLoader(ASVDataset(str(tmp_path / "train.txt"), str(d)), batch_size=1, shuffle=False)
+    ev = DataLoader(ASVDataset(str(tmp_path / "eval.txt"), str(d), eval=True), batch_size=1, shuffle=False)
+    e1, l1 = embed_dataset(model, ev, "cuda", 1)
+    e3, l3 = embed_dataset(model, ev, "cuda", 3)
+    torch.testing.assert_close(e3, e1, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(l3, l1, rtol=2e-4, atol=2e-4)
+    out = {}
+    for bs in (1, 3):
+        ref_emb, thr = create_reference_embedding2(model, tr, "cuda", cache=False, batch_size=bs)
+        score_eval_set_1c2(model, ev, "cuda", ref_emb, thr, path="scores_%d.txt" % bs, batch_size=bs)
+        out[bs] = (ref_emb, float(thr), [l.split(",") for l in open("scores_%d.txt" % bs).read().splitlines()])
+    torch.testing.assert_close(out[3][0], out[1][0], rtol=2e-4, atol=2e-4)
+    assert abs(out[3][1] - out[1][1]) < 2e-4 and len(out[3][2]) == len(lens)
+    for (d3, f3), (d1, f1) in zip(out[3][2], out[1][2]):
+        assert abs(float(d3) - float(d1)) < 2e-4
+    assert len(model.ssl_model.model._ws) <= 12 and len(model.backend._ws) <= 12
+
+
 @pytest.mark.parametrize("extra", [[], ["--backend", "senet"], ["--finetuned"], ["--rawboost_algo", "5", "--rawboost_on_gpu"]])
 def test_oc_training_entry_point_runs_and_saves_checkpoint(tmp_path, monkeypatch, extra):
     """python -m occm_amd.oc_training on a tiny synthetic corpus (PFDataset groups of 12 from 16-bit wav files): one epoch through the

@@ -107,3 +107,35 @@ def test_oracle_training_steps_match_reference_loop():
         if k.startswith("p_") and GT[k].dtype.kind == "f":
             np.testing.assert_allclose(q[k[2:]].detach().numpy(), GT[k], rtol=0, atol=6.1e-4)
     assert int(q["first_bn.num_batches_tracked"]) == int(GT["p_first_bn.num_batches_tracked"]) == 3
+
+
+@pytest.mark.parametrize("tag,shape,seed", [("a", (3, 1, 48, 1024), 21), ("b", (2, 1, 199, 1024), 22)])
+def test_lcnn_oracle_matches_reference_vectors(tag, shape, seed):
+    """oracle/lcnn_ref.py vs tests/golden/lcnn.npz (models/lcnn.py lcnn_net(asoftmax=False) run by gen_golden.py): eval logits, train-mode
+    logits with the dropouts at p = 0, BatchNorm running statistics, every parameter-gradient norm (the never-applied ``group.bn`` has
+    none) and three whole gradients."""
+    from oracle import lcnn_ref
+    GL = golden("lcnn.npz")
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=g)
+    p = fill_like(lcnn_ref.param_shapes(), seed=4)
+    with torch.no_grad():
+        y = lcnn_ref.lcnn_forward(x, p, train=False)
+    np.testing.assert_allclose(y.numpy(), GL["eval_" + tag], rtol=1e-4, atol=1e-5)
+    q = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in p.items()}
+    y = lcnn_ref.lcnn_forward(x, q, train=True, masks={})
+    np.testing.assert_allclose(y.detach().numpy(), GL["train_" + tag], rtol=2e-4, atol=2e-5)
+    wgt = torch.randn(y.shape, generator=g)
+    np.testing.assert_array_equal(wgt.numpy(), GL["train_wgt_" + tag])
+    (y * wgt).sum().backward()
+    for k in ("layer2.2.running_mean", "layer2.2.running_var", "layer3.2.running_mean", "layer3.2.running_var"):
+        np.testing.assert_allclose(q[k].numpy(), GL["rs_%s_%s" % (tag, k)], rtol=1e-4, atol=1e-6)
+    names, norms = list(GL["gradnames_" + tag]), GL["gradnorms_" + tag]
+    dead = sorted(n for n, v in zip(names, norms) if v < 0)
+    assert dead == sorted("layer%d.0.bn.%s" % (i, w) for i in (2, 3) for w in ("weight", "bias"))
+    for n, v in zip(names, norms):
+        if v >= 0:
+            assert abs(float(q[n].grad.norm()) - v) <= 2e-3 * v + 1e-6, (n, float(q[n].grad.norm()), v)
+    for k in ("layer1.0.filter.weight", "layer3.0.conv.filter.weight", "fc0.0.filter.0.weight"):
+        ref = GL["grad_%s_%s" % (tag, k)]
+        np.testing.assert_allclose(q[k].grad.numpy(), ref, rtol=2e-3, atol=max(2e-3 * np.abs(ref).max(), 1e-7))
