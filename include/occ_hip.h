@@ -188,6 +188,11 @@ int occ_act_bwd(const float* dy, const float* y, float* dx, int act, int64_t n, 
 /* nn.Dropout: y = x*mask/(1-p); generate != 0 draws the keep-mask (Philox) and stores it, else uses the given mask. */
 int occ_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t stream_id,
                 int generate, void* stream);
+/* The same draw with the step counter in DEVICE memory: Philox stream id = (*step << 8) + site (site < 256), i.e. exactly
+ * occ_dropout(..., stream_id = (step << 8) + site, generate = 1).  A training step captured in a HIP graph then draws fresh masks on
+ * every replay; occ_add_u64 (captured with it) advances the counter.                                                       */
+int occ_dropout_step(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, const uint64_t* step, uint64_t site, void* stream);
+int occ_add_u64(uint64_t* counter, uint64_t v, void* stream);
 /* F.max_pool2d(LL(x).transpose(1,2).unsqueeze(1), (3,3)) (sslassist.py:512-514): y [B,T,F] -> out [B,F/3,T/3] written
  * with element stride out_c, idx = window argmax; bwd scatters dout back into dy [B,T,F] (pre-zeroed).   */
 int occ_stem_pool_fwd(const float* y, float* out, uint8_t* idx, int64_t B, int64_t T, int64_t F, int64_t out_c, void* stream);

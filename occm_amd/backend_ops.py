@@ -109,6 +109,16 @@ def dropout(x, y, mask, p, seed, stream_id, generate):
     return y
 
 
+def dropout_step(x, y, mask, p, seed, step_dev, site):
+    """Keep-mask drawn on the device from (seed, *step_dev, site): the graph-capturable form of ``dropout(..., generate=True)``."""
+    check(lib().occ_dropout_step(_a(x), _a(y), _a(mask), x.numel(), float(p), int(seed), _a(step_dev), int(site), stream_ptr()), "occ_dropout_step")
+    return y
+
+
+def add_u64(counter, v=1):
+    check(lib().occ_add_u64(_a(counter), int(v), stream_ptr()), "occ_add_u64")
+
+
 def stem_pool_fwd(y, out, idx, B, T, F, out_c=1):
     check(lib().occ_stem_pool_fwd(_a(y), _a(out), _a(idx), B, T, F, out_c, stream_ptr()), "occ_stem_pool_fwd")
 

@@ -81,8 +81,10 @@ __device__ __forceinline__ void philox_r(uint32_t (&c)[4], uint32_t k0, uint32_t
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 // mask[i] = keep ? 1 : 0 (generated when gen != 0), y = x * mask / (1-p)
+// step (optional, device): the Philox stream id becomes (*step << 8) + sid, so a captured HIP graph draws fresh masks on every replay
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ mask, long long n, float p,
-                               uint64_t seed, uint64_t sid, int gen) {
+                               uint64_t seed, uint64_t sid, int gen, const uint64_t* __restrict__ step) {
+    if (step) sid += *step << 8;
     const float sc = 1.0f / (1.0f - p);
     const long long nq = (n + 3) / 4;
     for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
@@ -1106,8 +1108,26 @@ int occ_act_bwd(const float* dy, const float* y, float* dx, int act, int64_t n, 
 int occ_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t stream_id, int generate, void* stream) {
     OCC_CHECK_ARG(x && y && mask && n >= 0 && p >= 0.f && p < 1.f, "occ_dropout: bad argument");
     if (n == 0) return OCC_OK;
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(occ_cdiv(n, 4))), dim3(BT), 0, (hipStream_t)stream, x, y, mask, (long long)n, p, seed, stream_id, generate);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(occ_cdiv(n, 4))), dim3(BT), 0, (hipStream_t)stream, x, y, mask, (long long)n, p, seed, stream_id, generate,
+                       (const uint64_t*)nullptr);
     OCC_LAUNCH_CHECK("occ_dropout");
+    return OCC_OK;
+}
+
+__global__ void add_u64_kernel(uint64_t* p, uint64_t v) { *p += v; }
+
+int occ_dropout_step(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, const uint64_t* step, uint64_t site, void* stream) {
+    OCC_CHECK_ARG(x && y && mask && step && n >= 0 && p >= 0.f && p < 1.f && site < 256, "occ_dropout_step: bad argument");
+    if (n == 0) return OCC_OK;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(occ_cdiv(n, 4))), dim3(BT), 0, (hipStream_t)stream, x, y, mask, (long long)n, p, seed, site, 1, step);
+    OCC_LAUNCH_CHECK("occ_dropout_step");
+    return OCC_OK;
+}
+
+int occ_add_u64(uint64_t* counter, uint64_t v, void* stream) {
+    OCC_CHECK_ARG(counter, "occ_add_u64: null pointer");
+    hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, v);
+    OCC_LAUNCH_CHECK("occ_add_u64");
     return OCC_OK;
 }
 int occ_stem_pool_fwd(const float* y, float* out, uint8_t* idx, int64_t B, int64_t T, int64_t F, int64_t out_c, void* stream) {

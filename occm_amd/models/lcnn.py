@@ -57,6 +57,8 @@ def lcnn_param_table():
 
 
 class LcnnBackend:
+    graph_safe = True           # a train step makes no host decision and draws its masks from device-side counters: OcTrainer may replay it from a HIP graph
+
     def __init__(self, params=None, device="cuda", seed=4, compute="f32"):
         """compute: "f32" (exact-f32 MFMA, the parity path) or "bf16" (operands rounded to bf16 on the way into LDS wherever K and the
         operand strides allow, f32 accumulate); activations, parameters and gradients are f32 in memory either way."""
@@ -89,6 +91,7 @@ class LcnnBackend:
         self.bn_sums = torch.empty(512, device=self.device)
         self._ws, self.ctx = {}, None
         self.rng_seed, self.rng_step = seed, 0
+        self.rng_step_dev = torch.zeros(1, device=self.device, dtype=torch.int64)      # the step counter the device-drawn masks are keyed by
         self.load_reference_params(params if params is not None else synthetic_lcnn_params(seed))
 
     # ---------------------------------------------------------------------------- checkpoint layouts --
@@ -206,7 +209,7 @@ class LcnnBackend:
             else:
                 mask = torch.empty(B, o2, device=self.device, dtype=torch.uint8)
                 self._site_id += 1
-                K.dropout(z, z, mask, pd, self.rng_seed, (self.rng_step << 8) + self._site_id, generate=True)
+                K.dropout_step(z, z, mask, pd, self.rng_seed, self.rng_step_dev, self._site_id)
         h = self._e(B, o2 // 2)
         check(lib().occ_mfm_fwd(ptr(z), ptr(h), _rm(rowmap(B, 0, o2 // 2)), B, o2 // 2, stream_ptr()), "occ_mfm_fwd")
         c[site] = (x, z, mask)
@@ -292,6 +295,7 @@ class LcnnBackend:
         self.ctx = c if train else None
         if train:
             self.rng_step += 1
+            K.add_u64(self.rng_step_dev, 1)
         return out[:, :2].contiguous()
 
     def _fc3_pad(self):

@@ -64,6 +64,8 @@ def _cp(c):
 
 
 class SeResNet34Backend:
+    graph_safe = True           # a train step makes no host decision and draws its masks from device-side counters: OcTrainer may replay it from a HIP graph
+
     def __init__(self, params=None, device="cuda", seed=1, compute="f32"):
         """compute: "f32" (exact-f32 MFMA, the parity path) or "bf16" (operands rounded to bf16 on the way into LDS, bf16 MFMA, f32
         accumulate; weight gradients likewise) -- activations, parameters and gradients stay f32 in memory either way."""

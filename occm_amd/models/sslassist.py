@@ -92,6 +92,7 @@ _AW_ROW = {"att_weight": 0, "att_weight11": 0, "att_weight22": 1, "att_weight12"
 
 class AasistBackend:
     """Explicit forward/backward engine of the AASIST graph back-end (everything after the SSL features)."""
+    graph_safe = True           # a train step makes no host decision and draws its masks from device-side counters: OcTrainer may replay it from a HIP graph
 
     def __init__(self, params=None, device="cuda", seed=0, compute="f32"):
         """compute: "f32" = exact-f32 MFMA everywhere (parity path); "bf16" = Linear / Conv2d forward and input-gradient
@@ -144,7 +145,8 @@ class AasistBackend:
         self._ws = {}
         self.ctx = None
         self.rng_seed = seed
-        self.rng_step = 0
+        self.rng_step = 0                       # host mirror of the device counter below (one per train-mode forward)
+        self.rng_step_dev = torch.zeros(1, device=self.device, dtype=torch.int64)
         self.load_reference_params(params if params is not None else synthetic_backend_params(seed), strict_buffers=False)
 
     def _view(self, flat, key):
@@ -281,7 +283,7 @@ class AasistBackend:
         m = torch.empty(x.shape, device=self.device, dtype=torch.uint8)
         y = self._e(*x.shape)
         self._site_id += 1
-        K.dropout(x, y, m, p, self.rng_seed, (self.rng_step << 8) + self._site_id, generate=True)
+        K.dropout_step(x, y, m, p, self.rng_seed, self.rng_step_dev, self._site_id)
         return y, m
 
     def _drop_mask_only(self, shape, site, p, train, masks):
@@ -293,7 +295,7 @@ class AasistBackend:
         m = torch.empty(shape, device=self.device, dtype=torch.uint8)
         dummy = self._e(*shape)
         self._site_id += 1
-        K.dropout(dummy, dummy, m, p, self.rng_seed, (self.rng_step << 8) + self._site_id, generate=True)
+        K.dropout_step(dummy, dummy, m, p, self.rng_seed, self.rng_step_dev, self._site_id)
         return m
 
     # ------------------------------------------------------------------------- conv geometry --
@@ -409,6 +411,7 @@ class AasistBackend:
         self.ctx = c if train else None
         if train:
             self.rng_step += 1
+            K.add_u64(self.rng_step_dev, 1)     # on the stream, so a captured step advances it on every replay
         return emb, logits
 
     # ---- GraphAttentionLayer (sslassist.py:58-151) ------------------------------------------------

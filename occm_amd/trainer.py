@@ -13,8 +13,13 @@ class OcTrainer:
     0.0 / 1.0 (oc_training.py:380-381); the SE-ResNet script uses 0.1 / 0.9 (test_dataloader_v2.py:127)."""
 
     def __init__(self, model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=False, group_size=None, dropout_masks=None, rawboost_algo=0,
-                 rawboost_args=None, seed=0, rank=0):
+                 rawboost_args=None, seed=0, rank=0, graph_backend=True):
+        """graph_backend: replay the back-end section of a step (zero_grad, forward, losses, backward: ~560 small launches for AASIST) from a
+        HIP graph once a batch shape has come twice in a row (fixed-length training); until then, and for every other shape, steps run eagerly.  Needs device-drawn dropout masks
+        (``dropout_masks=None``): injected masks run eagerly."""
         self.model = model
+        self.graph_backend = graph_backend
+        self._graphs, self._last_key = {}, None
         # every data-parallel rank draws its own augmentation parameters: the rank is part of the RawBoost seed
         self.rawboost_algo, self.rawboost_args, self.seed, self.nstep = rawboost_algo, rawboost_args, seed * 4096 + rank, 0
         self.dropout_masks = dropout_masks      # None: draw masks on the device (normal training); {}: no dropout; dict: injected keep-masks
@@ -91,28 +96,63 @@ class OcTrainer:
         self._pref = None
         if next_wav is not None:
             self._prefetch(next_wav, step_idx + 1)
+        lc, ld, _ = self._backend_section(feats, labels, False)
+        self.reducer.all_reduce()
+        self.opt.step(self._grads, grad_scale=self.reducer.grad_scale)
+        self.last = (lc, ld)
+        return lc, ld
+
+    def _backend_eager(self, feats, labels, want_dfeats):
+        be = self.be
         be.zero_grad()
         emb, logits = be.forward(feats, train=True, masks=self.dropout_masks)
         B = emb.shape[0]
         ng = 1 if not self.group_size else B // self.group_size
         lc, demb = ops.compactness_loss(emb, n_groups=ng, group=self.group_size or B, scale=self.w_c, want_grad=True)
         ld, dlog = ops.ce_loss(logits, labels, scale=self.w_d, want_grad=True)
-        be.backward(demb, dlog)
-        self.reducer.all_reduce()
-        self.opt.step(self._grads, grad_scale=self.reducer.grad_scale)
-        self.last = (lc, ld)
-        return lc, ld
+        dfeats = be.backward(demb, dlog, want_dfeats=True) if want_dfeats else be.backward(demb, dlog)
+        return lc, ld, dfeats
+
+    def _backend_section(self, feats, labels, want_dfeats):
+        """zero_grad -> back-end forward -> losses -> back-end backward, eagerly or as one HIP-graph replay (same kernels, same order,
+        same arithmetic; the dropout masks come from a device-side step counter that the graph itself advances)."""
+        if not (self.graph_backend and self.dropout_masks is None and getattr(self.be, "graph_safe", False)):
+            return self._backend_eager(feats, labels, want_dfeats)
+        key = (tuple(feats.shape), str(feats.dtype), bool(want_dfeats))
+        rec = self._graphs.get(key)
+        if rec is not None and rec["graph"] is not None:
+            rec["feats"].copy_(feats); rec["labels"].copy_(labels)
+            rec["graph"].replay()
+            self._last_key = key
+            return rec["out"]
+        out = self._backend_eager(feats, labels, want_dfeats)
+        repeat = self._last_key == key
+        self._last_key = key
+        if rec is None or not repeat:
+            # capture only when a shape comes twice in a row (fixed-length training): variable-length groups would pay a capture
+            # per step for graphs that are evicted before they are replayed
+            self._graphs[key] = {"graph": None}
+            while len(self._graphs) > 4:
+                self._graphs.pop(next(iter(self._graphs)))
+            return out
+        # this shape again, back to back: capture the section for the following steps (capturing enqueues nothing)
+        rec["feats"], rec["labels"] = feats.clone(), labels.clone()
+        rec["keep"] = dict(getattr(self.be, "_ws", {}))     # the persistent (bordered) buffers the graph writes to must outlive the engine's cache
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        step_before = getattr(self.be, "rng_step", 0)
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            rec["out"] = self._backend_eager(rec["feats"], rec["labels"], want_dfeats)
+        if hasattr(self.be, "rng_step"):
+            self.be.rng_step = step_before               # the host mirror counts executed steps, not captured ones
+        rec["graph"] = g
+        return out
 
     def _step_finetune(self, wav, labels):
         be, fe = self.be, self.fe
         feats = fe.forward_train(wav)
-        be.zero_grad(); fe.zero_grad()
-        emb, logits = be.forward(feats, train=True, masks=self.dropout_masks)
-        B = emb.shape[0]
-        ng = 1 if not self.group_size else B // self.group_size
-        lc, demb = ops.compactness_loss(emb, n_groups=ng, group=self.group_size or B, scale=self.w_c, want_grad=True)
-        ld, dlog = ops.ce_loss(logits, labels, scale=self.w_d, want_grad=True)
-        dfeats = be.backward(demb, dlog, want_dfeats=True)
+        fe.zero_grad()
+        lc, ld, dfeats = self._backend_section(feats, labels, True)
         # each transformer layer's 50 MB of gradients go to RCCL as soon as that layer's backward is enqueued (last layer first);
         # the conv stack, the back-end and anything left over follow at the end
         fe.backward(dfeats, grad_ready=self.reducers[1].reduce_range if self.reducers[1].world > 1 else None)

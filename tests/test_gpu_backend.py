@@ -370,6 +370,47 @@ def test_trainer_prefetch_pipeline_equals_sequential_steps():
     assert abs(a - c) <= 0.02 * abs(a) and abs(b - d) <= 0.02 * abs(b), (seq, pip)
 
 
+def test_backend_section_replayed_from_hip_graph_equals_eager():
+    """OcTrainer replays zero_grad -> AASIST forward -> losses -> backward from a HIP graph from the third time a batch shape is seen.
+    With fixed parameters the replay must reproduce the eager section for new inputs: losses, every parameter gradient and the feature
+    gradient (to the f32 atomics' noise), with dropout masks keyed by the device-side step counter the graph itself advances -- the same
+    counter value gives the same masks, the next value different ones."""
+    from occm_amd.models import xlsr
+    from occm_amd.models.sslassist import AModel
+    from occm_amd.trainer import OcTrainer
+    cfg = xlsr.XlsrConfig(dim=1024, ffn=512, heads=16, layers=1)
+    model = AModel(None, "cuda", ssl_cfg=cfg, seed=0, synthetic_ssl=True)
+    model.train()
+    tr = OcTrainer(model, lr=1e-4, w_compact=0.1, w_descr=0.9, group_size=12)
+    be = tr.be
+    labels = (torch.arange(12) >= 6).long().cuda()
+
+    def run(feats, graph, step):
+        be.rng_step_dev.fill_(step)
+        tr.graph_backend = graph
+        lc, ld, df = tr._backend_section(feats, labels, True)
+        assert int(be.rng_step_dev) == step + 1
+        return float(lc), float(ld), df.clone(), be.G.clone()
+
+    key = None
+    for i in range(4):
+        feats = _r(12, 199, 1024, seed=70 + i).cuda()
+        e = run(feats, False, 100 + i)
+        g = run(feats, True, 100 + i)
+        key = key or next(iter(tr._graphs))
+        assert (tr._graphs[key]["graph"] is not None) == (i >= 1)            # captured on the second sighting, replayed from the third
+        assert abs(e[0] - g[0]) <= 1e-5 * abs(e[0]) + 1e-7 and abs(e[1] - g[1]) <= 1e-5 * abs(e[1]) + 1e-7, (i, e[:2], g[:2])
+        torch.testing.assert_close(g[2], e[2], rtol=1e-3, atol=1e-4 * float(e[2].abs().max()))
+        torch.testing.assert_close(g[3], e[3], rtol=1e-3, atol=1e-4 * float(e[3].abs().max()))
+    a = run(feats, True, 500)
+    b = run(feats, True, 500)
+    c = run(feats, True, 501)
+    assert abs(a[1] - b[1]) <= 1e-5 * abs(a[1]) and abs(a[1] - c[1]) > 1e-6 * abs(a[1]), (a[:2], b[:2], c[:2])     # masks: same step same draw, next step another
+    # a different batch shape falls back to eager and gets its own record
+    run(_r(12, 150, 1024, seed=9).cuda(), True, 7)
+    assert len(tr._graphs) == 2
+
+
 def test_training_steps_match_reference_loop_golden():
     """tests/golden/train_steps.npz (three steps of the reference's own loop body on fixed features, dropout off) retraced through
     the C ABI: back-end forward/backward (exact-f32 MFMA), loss kernels, occ_adam_multi.  Tolerances as in the oracle's test."""
