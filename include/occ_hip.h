@@ -359,11 +359,13 @@ int occ_conv0_ln_gelu_bwd(const float* wav, const float* w, const float* bias, c
                           int dact_dtype, float* dw, float* dbias, float* dgamma, float* dbeta, int64_t B, int64_t L, int64_t Tout,
                           int64_t C, int64_t k, int64_t stride, float eps, void* stream);
 /* weight_norm(dim=2) of fairseq's pos_conv: v f32 [O,I,K], g f32 [K] -> bf16 GEMM operands w_fwd [G][O/G][K][I] and (optional)
- * w_bwd [G][I][K][O/G] (taps reversed, for the input gradient), norms f32 [K]; bwd maps a packed-layout weight gradient to dv, dg. */
+ * w_bwd [G][I][K][O/G] (taps reversed, for the input gradient), norms f32 [K]; bwd maps a packed-layout weight gradient to dv, dg.
+ * scratch (optional, caller-owned): with at least 64*K floats (pack) / (O+1)*K floats (bwd) and 256 % K == 0 the coalesced kernels run
+ * (LDS transposes, fixed-order partial sums); NULL = one workgroup per tap with strided reads.                                   */
 int occ_weight_norm_pack(const float* v, const float* g, void* w_fwd, void* w_bwd, float* norms, int64_t O, int64_t I, int64_t K,
-                         int64_t G, void* stream);
+                         int64_t G, float* scratch, int64_t scratch_floats, void* stream);
 int occ_weight_norm_bwd(const float* v, const float* g, const float* norms, const float* dw_packed, float* dv, float* dg, int64_t O,
-                        int64_t I, int64_t K, int64_t G, void* stream);
+                        int64_t I, int64_t K, int64_t G, float* scratch, int64_t scratch_floats, void* stream);
 /* dx_bf16 (optional): a bf16 copy of dx for the next input-gradient GEMMs.                                             */
 int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16,
                       float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, float* scratch, int64_t scratch_floats, void* stream);

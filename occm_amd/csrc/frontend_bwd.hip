@@ -524,6 +524,114 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
     }
 }
 
+
+// ---- coalesced forms of the two kernels above (taken when the caller passes scratch and 256 % K == 0) ---------------------------------
+// v [O*I rows][K] has the taps innermost, the GEMM layouts have them outermost: one workgroup per tap reads every element with a
+// stride of K floats (4 of every 512 bytes fetched: 331 us / 547 us for the 8.4 M weights of XLS-R's positional conv).  Here every
+// global access is a contiguous row segment and the (i,k) <-> (k,i) / (n,k) <-> (k,n) transposes happen in LDS (row pitch + 1).
+__global__ __launch_bounds__(256) void wn_sumsq_kernel(const float* __restrict__ v, float* __restrict__ partial, long long rows, int K) {
+    __shared__ float red[256];
+    const int k = threadIdx.x % K, lr = threadIdx.x / K, rpp = 256 / K;
+    const long long per = (rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s = 0.f;
+    for (long long r = r0 + lr; r < r1; r += rpp) { const float x = v[r * K + k]; s += x * x; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float t = 0.f;
+        for (int j = 0; j < rpp; ++j) t += red[j * K + threadIdx.x];
+        partial[(long long)blockIdx.x * K + threadIdx.x] = t;
+    }
+}
+// one workgroup per output channel o: wf[o][k][i] = bf16(v[o][i][k] * g[k] / ||v_k||)
+__global__ __launch_bounds__(256) void wn_pack_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ partial, int S,
+                                                         unsigned short* __restrict__ wf, float* __restrict__ norms, int I, int K) {
+    extern __shared__ float wn_lds[];
+    float* sc = wn_lds;                 // [K]
+    float* tile = wn_lds + K;           // [I][K + 1]
+    const long long o = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float t = 0.f;
+        for (int j = 0; j < S; ++j) t += partial[(long long)j * K + k];
+        const float nrm = sqrtf(t);
+        sc[k] = g[k] / nrm;
+        if (o == 0) norms[k] = nrm;
+    }
+    for (int idx = threadIdx.x; idx < I * K; idx += 256) { const int i = idx / K, k = idx - i * K; tile[i * (K + 1) + k] = v[(o * I + i) * K + k]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < I * K; idx += 256) {
+        const int k = idx / I, i = idx - k * I;
+        wf[(o * K + k) * I + i] = f32_to_bf16_bits(tile[i * (K + 1) + k] * sc[k]);
+    }
+}
+// one workgroup per (group gi, input channel i): wb[gi][i][K-1-k][n] = bf16(w[(gi,n)][i][k])
+__global__ __launch_bounds__(256) void wn_pack_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ norms,
+                                                         unsigned short* __restrict__ wb, int I, int K, int cgn) {
+    extern __shared__ float wn_lds[];
+    float* sc = wn_lds;                 // [K]
+    float* tile = wn_lds + K;           // [cgn][K + 1]
+    const long long gi = blockIdx.x / I, i = blockIdx.x - gi * I;
+    for (int k = threadIdx.x; k < K; k += 256) sc[k] = g[k] / norms[k];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < cgn * K; idx += 256) {
+        const int n = idx / K, k = idx - n * K;
+        tile[n * (K + 1) + k] = v[((gi * cgn + n) * I + i) * K + k] * sc[k];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < K * cgn; idx += 256) {
+        const int j = idx / cgn, n = idx - j * cgn;
+        wb[((gi * I + i) * K + j) * cgn + n] = f32_to_bf16_bits(tile[n * (K + 1) + (K - 1 - j)]);
+    }
+}
+// backward: per output channel o, partial[o][k] = sum_i dWp[o][k][i] * v[o][i][k]
+__global__ __launch_bounds__(256) void wn_bwd_dot_kernel(const float* __restrict__ v, const float* __restrict__ dwp, float* __restrict__ partial, int I, int K) {
+    extern __shared__ float wn_lds[];
+    float* tile = wn_lds;               // [K][I + 1]
+    float* red = wn_lds + K * (I + 1);  // [256]
+    const long long o = blockIdx.x;
+    for (int idx = threadIdx.x; idx < K * I; idx += 256) { const int k = idx / I, i = idx - k * I; tile[k * (I + 1) + i] = dwp[(o * K + k) * I + i]; }
+    __syncthreads();
+    const int k = threadIdx.x % K, lr = threadIdx.x / K, rpp = 256 / K;
+    float s = 0.f;
+    for (int i = lr; i < I; i += rpp) s += tile[k * (I + 1) + i] * v[(o * I + i) * K + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float t = 0.f;
+        for (int j = 0; j < rpp; ++j) t += red[j * K + threadIdx.x];
+        partial[o * K + threadIdx.x] = t;
+    }
+}
+// dot[k] = sum_o partial[o][k] (fixed order); dg[k] += dot / ||v_k||
+__global__ __launch_bounds__(256) void wn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ norms, float* __restrict__ dot,
+                                                             float* __restrict__ dg, int O, int K) {
+    __shared__ float red[4];
+    const int k = blockIdx.x;
+    float s = 0.f;
+    for (int o = threadIdx.x; o < O; o += 256) s += partial[(long long)o * K + k];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { const float d = red[0] + red[1] + red[2] + red[3]; dot[k] = d; dg[k] += d / norms[k]; }
+}
+// dv[o][i][k] += g/||v|| * (dWp[o][k][i] - v * dot / ||v||^2)
+__global__ __launch_bounds__(256) void wn_bwd_apply_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ norms,
+                                                          const float* __restrict__ dwp, const float* __restrict__ dot, float* __restrict__ dv, int I, int K) {
+    extern __shared__ float wn_lds[];
+    float* tile = wn_lds;               // [K][I + 1]
+    float* a = wn_lds + K * (I + 1);    // [K] g / nrm
+    float* b = a + K;                   // [K] dot / nrm^2
+    const long long o = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += 256) { const float nrm = norms[k]; a[k] = g[k] / nrm; b[k] = dot[k] / (nrm * nrm); }
+    for (int idx = threadIdx.x; idx < K * I; idx += 256) { const int k = idx / I, i = idx - k * I; tile[k * (I + 1) + i] = dwp[(o * K + k) * I + i]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < I * K; idx += 256) {
+        const int i = idx / K, k = idx - i * K;
+        const long long at = (o * I + i) * K + k;
+        dv[at] += a[k] * (tile[k * (I + 1) + i] - v[at] * b[k]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -647,18 +755,36 @@ int occ_conv0_ln_gelu_bwd(const float* wav, const float* w, const float* bias, c
     return OCC_OK;
 }
 
-int occ_weight_norm_pack(const float* v, const float* g, void* w_fwd, void* w_bwd, float* norms, int64_t O, int64_t I, int64_t K, int64_t G, void* stream) {
+int occ_weight_norm_pack(const float* v, const float* g, void* w_fwd, void* w_bwd, float* norms, int64_t O, int64_t I, int64_t K, int64_t G, float* scratch,
+                         int64_t scratch_floats, void* stream) {
     OCC_CHECK_ARG(v && g && w_fwd && norms && O >= 1 && I >= 1 && K >= 1 && G >= 1 && O % G == 0, "occ_weight_norm_pack: bad argument");
-    hipLaunchKernelGGL(weight_norm_pack_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, v, g, (unsigned short*)w_fwd, (unsigned short*)w_bwd, norms,
-                       (int)O, (int)I, (int)K, (int)G);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t cgn = O / G, S = 64;
+    const size_t lds_f = (size_t)(K + I * (K + 1)) * 4, lds_b = (size_t)(K + cgn * (K + 1)) * 4;
+    if (scratch && scratch_floats >= S * K && K <= 256 && 256 % K == 0 && lds_f <= 64 * 1024 && lds_b <= 64 * 1024) {
+        hipLaunchKernelGGL(wn_sumsq_kernel, dim3((unsigned)S), dim3(256), 0, s, v, scratch, (long long)(O * I), (int)K);
+        hipLaunchKernelGGL(wn_pack_fwd_kernel, dim3((unsigned)O), dim3(256), lds_f, s, v, g, (const float*)scratch, (int)S, (unsigned short*)w_fwd, norms, (int)I, (int)K);
+        if (w_bwd) hipLaunchKernelGGL(wn_pack_bwd_kernel, dim3((unsigned)(G * I)), dim3(256), lds_b, s, v, g, (const float*)norms, (unsigned short*)w_bwd, (int)I, (int)K, (int)cgn);
+    } else {
+        hipLaunchKernelGGL(weight_norm_pack_kernel, dim3((unsigned)K), dim3(256), 0, s, v, g, (unsigned short*)w_fwd, (unsigned short*)w_bwd, norms, (int)O, (int)I, (int)K, (int)G);
+    }
     OCC_LAUNCH_CHECK("occ_weight_norm_pack");
     return OCC_OK;
 }
 
 int occ_weight_norm_bwd(const float* v, const float* g, const float* norms, const float* dw_packed, float* dv, float* dg, int64_t O, int64_t I, int64_t K,
-                        int64_t G, void* stream) {
+                        int64_t G, float* scratch, int64_t scratch_floats, void* stream) {
     OCC_CHECK_ARG(v && g && norms && dw_packed && dv && dg && O >= 1 && I >= 1 && K >= 1 && G >= 1 && O % G == 0, "occ_weight_norm_bwd: bad argument");
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, v, g, norms, dw_packed, dv, dg, (int)O, (int)I, (int)K, (int)G);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds_d = (size_t)(K * (I + 1) + 256) * 4, lds_a = (size_t)(K * (I + 1) + 2 * K) * 4;
+    if (scratch && scratch_floats >= O * K + K && K <= 256 && 256 % K == 0 && lds_d <= 64 * 1024 && lds_a <= 64 * 1024) {
+        float* dot = scratch + O * K;
+        hipLaunchKernelGGL(wn_bwd_dot_kernel, dim3((unsigned)O), dim3(256), lds_d, s, v, dw_packed, scratch, (int)I, (int)K);
+        hipLaunchKernelGGL(wn_bwd_finalize_kernel, dim3((unsigned)K), dim3(256), 0, s, (const float*)scratch, norms, dot, dg, (int)O, (int)K);
+        hipLaunchKernelGGL(wn_bwd_apply_kernel, dim3((unsigned)O), dim3(256), lds_a, s, v, g, norms, dw_packed, (const float*)dot, dv, (int)I, (int)K);
+    } else {
+        hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)K), dim3(256), 0, s, v, g, norms, dw_packed, dv, dg, (int)O, (int)I, (int)K, (int)G);
+    }
     OCC_LAUNCH_CHECK("occ_weight_norm_bwd");
     return OCC_OK;
 }

@@ -841,8 +841,9 @@ class XlsrFullFineTuner(XlsrFineTuner):
         pw = self.mp["proj.w"]
         ops.transpose_bf16(pw, self.wT["proj.w"], cfg.dim, 512, ld_src=512, ld_dst=cfg.dim)
         G, cg = cfg.pos_groups, cfg.dim // cfg.pos_groups
+        sc = ops.small_scratch()
         check(lib().occ_weight_norm_pack(ptr(self.mp["pos.v"]), ptr(self.mp["pos.g"]), ptr(self.w["pos.w"]), ptr(self.wT["pos.w"]), ptr(self.pos_norms),
-                                         cfg.dim, cg, cfg.pos_k, G, stream_ptr()), "occ_weight_norm_pack")
+                                         cfg.dim, cg, cfg.pos_k, G, ptr(sc), sc.numel(), stream_ptr()), "occ_weight_norm_pack")
 
     def _names_extra(self):
         out = {}
@@ -945,8 +946,9 @@ class XlsrFullFineTuner(XlsrFineTuner):
         for g in range(G):
             K.gemm_tn(M, cg, Kp * cg, du_in + g * cg * 2, dmap, xpad.data_ptr() + g * cg * 2, dmap, self.pos_dw[g], Kp * cg, b_seg=(Kp, cg, D),
                       colsum_out=self.mg["pos.b"][g * cg:(g + 1) * cg], a_bf16=True, b_bf16=True, bf16_mfma=True)   # operands are bf16 already: same products
+        sc = ops.small_scratch()
         check(lib().occ_weight_norm_bwd(ptr(self.mp["pos.v"]), ptr(self.mp["pos.g"]), ptr(self.pos_norms), ptr(self.pos_dw), ptr(self.mg["pos.v"]),
-                                        ptr(self.mg["pos.g"]), D, cg, Kp, G, stream_ptr()), "occ_weight_norm_bwd")
+                                        ptr(self.mg["pos.g"]), D, cg, Kp, G, ptr(sc), sc.numel(), stream_ptr()), "occ_weight_norm_bwd")
         xm = rowmap(M, 0, D)
         ops.gemm_raw(M, cg, Kp * cg, dupad, dmap, self.wT["pos.w"], Kp * cg, dx, xm, OCC_F32, bfc, R=dx, r_map=xm, r_dtype=OCC_F32,
                      a_seg=(Kp, cg, D), groups=(G, cg, cg * Kp * cg, cg))

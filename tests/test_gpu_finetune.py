@@ -300,3 +300,38 @@ def test_finetuner_train_mode_dropouts_layerdrop_and_feature_grad_mult_match_ora
     from occm_amd._lib import OccError
     with pytest.raises(OccError):
         ft.forward_train(wav.cuda())
+
+
+@pytest.mark.parametrize("O,I,K,G", [(64, 8, 128, 4), (1024, 64, 128, 16), (48, 12, 64, 2)])
+def test_weight_norm_pack_and_backward_coalesced_kernels(O, I, K, G):
+    """occ_weight_norm_pack / _bwd with caller scratch (LDS-transposing kernels, fixed-order partial sums) against torch's weight_norm
+    arithmetic and against the one-workgroup-per-tap kernels (scratch = NULL): GEMM-layout operands bit-equal up to the norm's
+    summation order, gradients to 1e-5."""
+    from occm_amd import ops
+    from occm_amd._lib import check, lib, ptr, stream_ptr
+    g_ = torch.Generator().manual_seed(O + K)
+    v = (0.05 * torch.randn(O, I, K, generator=g_)).requires_grad_(True)
+    g = (1.0 + 0.1 * torch.randn(K, generator=g_)).requires_grad_(True)
+    nrm = v.pow(2).sum(dim=(0, 1)).sqrt()
+    w = g * v / nrm                                                            # [O,I,K]
+    dwp = torch.randn(O, K, I, generator=g_)                                   # gradient in the GEMM layout [o][k][i]
+    (w.permute(0, 2, 1) * dwp).sum().backward()
+    cgn = O // G
+    wf_ref = w.detach().permute(0, 2, 1).contiguous()                          # [o][k][i]
+    wb_ref = w.detach().view(G, cgn, I, K).permute(0, 2, 3, 1).flip(2).contiguous()      # [G][i][K-1-k][n]
+    vd, gd, dwd = v.detach().cuda(), g.detach().cuda(), dwp.cuda()
+    res = []
+    for use_scratch in (True, False):
+        sc = ops.small_scratch() if use_scratch else None
+        wf = torch.empty(O, K, I, device="cuda", dtype=torch.bfloat16); wb = torch.empty(G, I, K, cgn, device="cuda", dtype=torch.bfloat16)
+        norms = torch.empty(K, device="cuda")
+        check(lib().occ_weight_norm_pack(ptr(vd), ptr(gd), ptr(wf), ptr(wb), ptr(norms), O, I, K, G, ptr(sc), sc.numel() if use_scratch else 0, stream_ptr()), "pack")
+        torch.testing.assert_close(norms.cpu(), nrm.detach(), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(wf.float().cpu(), wf_ref.bfloat16().float(), rtol=1e-2, atol=1e-6)
+        torch.testing.assert_close(wb.float().cpu(), wb_ref.bfloat16().float(), rtol=1e-2, atol=1e-6)
+        dv, dg = torch.ones(O, I, K, device="cuda"), torch.ones(K, device="cuda")           # accumulate semantics: start from 1
+        check(lib().occ_weight_norm_bwd(ptr(vd), ptr(gd), ptr(norms), ptr(dwd), ptr(dv), ptr(dg), O, I, K, G, ptr(sc), sc.numel() if use_scratch else 0, stream_ptr()), "bwd")
+        torch.testing.assert_close(dv.cpu() - 1, v.grad, rtol=1e-4, atol=1e-5 * float(v.grad.abs().max()) + 1e-6)
+        torch.testing.assert_close(dg.cpu() - 1, g.grad, rtol=1e-4, atol=1e-4 * float(g.grad.abs().max()))
+        res.append((wf, wb))
+    assert float((res[0][0].float() - res[1][0].float()).abs().max()) <= 1e-2 * float(res[1][0].float().abs().max())
