@@ -336,6 +336,11 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
 /* colsum (optional f32 [cols]): += column sums of src -- the bias gradient comes for free with the dY^T operand.           */
 int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
                        float* colsum, void* stream);
+/* n_jobs transposes dst[c, r] = bf16(src[r, c]) in ONE launch.  The job array lives in DEVICE memory (the caller builds it once: the
+ * operands of a model do not move), sorted by first_tile = number of 64x64 tiles of the jobs before it; total_tiles = their sum.
+ * src_dtype OCC_F32 or OCC_BF16.                                                                                           */
+typedef struct occ_transpose_job { const void* src; void* dst; int64_t rows, cols, ld_src, ld_dst, first_tile; int64_t src_dtype; } occ_transpose_job;
+int occ_transpose_bf16_batch(const occ_transpose_job* jobs_dev, int64_t n_jobs, int64_t total_tiles, void* stream);
 /* dx = LayerNorm'(x)^T dy (+ dres, the residual-branch gradient; dx may alias dres); dgamma += sum dy*xhat; dbeta += sum dy. */
 /* Same with the source rows addressed through a row map (strided conv windows, interiors of padded buffers).               */
 int occ_transpose_bf16_rows(const void* src, int src_dtype, const occ_rowmap* src_map, void* dst, int64_t rows, int64_t cols,

@@ -41,6 +41,36 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const TS* __restric
     }
 }
 
+// Many transposes in one launch (the W^T operands of a training step's input-gradient GEMMs: 112 small launches of 9-14 us each were
+// latency-bound at 1.5 TB/s).  jobs live in device memory; workgroup b finds its job by first_tile (ascending) and does one 64x64 tile.
+__global__ __launch_bounds__(256) void transpose_bf16_batch_kernel(const occ_transpose_job* __restrict__ jobs, int n_jobs) {
+    __shared__ unsigned short tile[64][66];
+    int lo = 0, hi = n_jobs - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].first_tile <= b) lo = mid; else hi = mid - 1; }
+    const occ_transpose_job j = jobs[lo];
+    const long long t = b - j.first_tile, tiles_x = (j.cols + 63) / 64;
+    const long long r0 = (t / tiles_x) * 64, c0 = (t % tiles_x) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const long long r = r0 + ty + 4 * i, c = c0 + tx;
+        unsigned short v = 0;
+        if (r < j.rows && c < j.cols) {
+            const long long so = r * j.ld_src + c;
+            v = j.src_dtype == OCC_F32 ? f32_to_bf16_bits(reinterpret_cast<const float*>(j.src)[so]) : reinterpret_cast<const unsigned short*>(j.src)[so];
+        }
+        tile[ty + 4 * i][tx] = v;
+    }
+    __syncthreads();
+    unsigned short* dst = reinterpret_cast<unsigned short*>(j.dst);
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const long long c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < j.cols && r < j.rows) dst[c * j.ld_dst + r] = tile[tx][ty + 4 * i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward over rows of width C (C % 8 == 0, C <= 2048), one wave per row, persistent waves:
 //   dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) (+ dres);  dgamma += sum dy*xhat;  dbeta += sum dy.
@@ -647,6 +677,13 @@ int occ_transpose_bf16_rows(const void* src, int src_dtype, const occ_rowmap* sr
     if (src_dtype == OCC_F32) hipLaunchKernelGGL(transpose_bf16_kernel<float>, grid, block, 0, s, (const float*)src, (unsigned short*)dst, (long long)rows, (long long)cols, sm, (long long)ld_dst, colsum);
     else hipLaunchKernelGGL(transpose_bf16_kernel<unsigned short>, grid, block, 0, s, (const unsigned short*)src, (unsigned short*)dst, (long long)rows, (long long)cols, sm, (long long)ld_dst, colsum);
     OCC_LAUNCH_CHECK("occ_transpose_bf16");
+    return OCC_OK;
+}
+
+int occ_transpose_bf16_batch(const occ_transpose_job* jobs_dev, int64_t n_jobs, int64_t total_tiles, void* stream) {
+    OCC_CHECK_ARG(jobs_dev && n_jobs >= 1 && n_jobs < (1 << 20) && total_tiles >= 1 && total_tiles < (1ll << 31), "occ_transpose_bf16_batch: bad argument");
+    hipLaunchKernelGGL(transpose_bf16_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, jobs_dev, (int)n_jobs);
+    OCC_LAUNCH_CHECK("occ_transpose_bf16_batch");
     return OCC_OK;
 }
 

@@ -438,14 +438,20 @@ class XlsrFineTuner(XlsrFrontend):
         from .._lib import check, lib, ptr, stream_ptr
         if cast:
             check(lib().occ_cast(ptr(self.P), OCC_F32, ptr(self.Wb), OCC_BF16_CODE, self.P.numel(), stream_ptr()), "occ_cast")
-        for name in self._encoder_names():
-            shp = self.tslots[name][1]
-            if name.endswith(".w"):
-                ops.transpose_bf16(self.mp[name], self.wT[name], shp[0], shp[1], ld_src=shp[1], ld_dst=shp[0])
+        if getattr(self, "_tbatch", None) is None:             # every W^T operand of the step in one launch, read from the bf16 mirror
+            self._tbatch = ops.TransposeBatch()
+            self._transpose_jobs(self._tbatch)
+        self._tbatch.run()
         if getattr(self, "fp8", False):
             self._fp8_weights()
             if self.ctx is None and self.drop_step > 0:
                 self.f8["warm"] = False                          # a whole step has been seen: every site has a measured |max|
+
+    def _transpose_jobs(self, tb):
+        for name in self._encoder_names():
+            shp = self.tslots[name][1]
+            if name.endswith(".w"):
+                tb.add(self.w[name], self.wT[name], shp[0], shp[1], ld_src=shp[1], ld_dst=shp[0])
 
     def export_params(self):
         """Trainable tensors back under their fairseq names (q/k/v split again)."""
@@ -822,24 +828,26 @@ class XlsrFullFineTuner(XlsrFineTuner):
         self.pos_norms = torch.empty(cfg.pos_k, device=dev, dtype=torch.float32)
         self.pos_dw = torch.empty(G, cg, cfg.pos_k * cg, device=dev, dtype=torch.float32)
 
+    def _transpose_jobs(self, tb):
+        super()._transpose_jobs(tb)
+        for i in range(1, 7):
+            k = CONV_LAYERS[i][1]
+            src = self.w["c%d.w" % i]                        # bf16 mirror of the master layout [n][tap][c]
+            es = 2
+            if k == 3:
+                we, wo = self.wT["c%d.we" % i], self.wT["c%d.wo" % i]
+                # dst[c][n] = src[n][tap][c]: a transpose of the [512 x 512] slice with row stride k*512
+                tb.add(src.data_ptr() + 2 * 512 * es, we, 512, 512, ld_src=k * 512, ld_dst=1024, src_dtype=OCC_BF16_CODE)
+                tb.add(src.data_ptr() + 0 * 512 * es, we.data_ptr() + 512 * 2, 512, 512, ld_src=k * 512, ld_dst=1024, src_dtype=OCC_BF16_CODE)
+                tb.add(src.data_ptr() + 1 * 512 * es, wo, 512, 512, ld_src=k * 512, ld_dst=512, src_dtype=OCC_BF16_CODE)
+            else:
+                tb.add(src, self.wT["c%d.wt" % i], 512, k * 512, ld_src=k * 512, ld_dst=512)
+        tb.add(self.w["proj.w"], self.wT["proj.w"], self.cfg.dim, 512, ld_src=512, ld_dst=self.cfg.dim)
+
     def refresh_operands(self, cast=True):
         super().refresh_operands(cast=cast)
         from .._lib import check, lib, ptr, stream_ptr
         cfg = self.cfg
-        for i in range(1, 7):
-            k = CONV_LAYERS[i][1]
-            src = self.mp["c%d.w" % i]                       # [n][tap][c]
-            es = 4
-            if k == 3:
-                we, wo = self.wT["c%d.we" % i], self.wT["c%d.wo" % i]
-                # dst[c][n] = src[n][tap][c]: a transpose of the [512 x 512] slice with row stride k*512
-                ops.transpose_bf16(src.data_ptr() + 2 * 512 * es, we, 512, 512, ld_src=k * 512, ld_dst=1024, src_dtype=OCC_F32)
-                ops.transpose_bf16(src.data_ptr() + 0 * 512 * es, we.data_ptr() + 512 * 2, 512, 512, ld_src=k * 512, ld_dst=1024, src_dtype=OCC_F32)
-                ops.transpose_bf16(src.data_ptr() + 1 * 512 * es, wo, 512, 512, ld_src=k * 512, ld_dst=512, src_dtype=OCC_F32)
-            else:
-                ops.transpose_bf16(src, self.wT["c%d.wt" % i], 512, k * 512, ld_src=k * 512, ld_dst=512)
-        pw = self.mp["proj.w"]
-        ops.transpose_bf16(pw, self.wT["proj.w"], cfg.dim, 512, ld_src=512, ld_dst=cfg.dim)
         G, cg = cfg.pos_groups, cfg.dim // cfg.pos_groups
         sc = ops.small_scratch()
         check(lib().occ_weight_norm_pack(ptr(self.mp["pos.v"]), ptr(self.mp["pos.g"]), ptr(self.w["pos.w"]), ptr(self.wT["pos.w"]), ptr(self.pos_norms),

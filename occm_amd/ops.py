@@ -152,6 +152,30 @@ def transpose_bf16_rows(src, src_map, dst, rows, cols, ld_dst, colsum=None, src_
     return dst
 
 
+class TransposeBatch:
+    """A fixed set of transposes dst[c, r] = bf16(src[r, c]) run as ONE launch (occ_transpose_bf16_batch).  add() takes tensors or int device
+    addresses; the job table is uploaded on the first run() and the operands must not move afterwards."""
+
+    def __init__(self):
+        self.jobs, self.tiles, self._dev = [], 0, None
+
+    def add(self, src, dst, rows, cols, ld_src=None, ld_dst=None, src_dtype=None):
+        sd = src_dtype if src_dtype is not None else dtype_code(src)
+        sp = src if isinstance(src, int) else src.data_ptr()
+        dp = dst if isinstance(dst, int) else dst.data_ptr()
+        self.jobs.append((sp, dp, int(rows), int(cols), int(ld_src or cols), int(ld_dst or dst.shape[-1]), self.tiles, int(sd)))
+        self.tiles += ((int(rows) + 63) // 64) * ((int(cols) + 63) // 64)
+        self._dev = None
+
+    def run(self):
+        if not self.jobs:
+            return
+        if self._dev is None:
+            import numpy as np
+            self._dev = torch.from_numpy(np.asarray(self.jobs, dtype=np.int64)).cuda()
+        check(lib().occ_transpose_bf16_batch(ptr(self._dev), len(self.jobs), self.tiles, stream_ptr()), "occ_transpose_bf16_batch")
+
+
 FP8_MAX = {_lib.OCC_FP8_E4M3: 448.0, _lib.OCC_FP8_E5M2: 57344.0}
 
 
