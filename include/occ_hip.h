@@ -170,6 +170,11 @@ typedef struct occ_gemm_tn_desc {
     void* workspace; int64_t workspace_bytes;
 } occ_gemm_tn_desc;
 int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream);
+/* Two weight gradients with the same reduction rows M (out-proj with qkv, fc2 with fc1 of one transformer layer) in ONE launch when both
+ * take the large bf16 kernel (N1, N2 multiples of 256, plain row maps, M % 64 == 0, d0's workspace): half the slab traffic and longer
+ * reduction pieces than two launches.  Anything else runs as occ_gemm_tn(d0) then occ_gemm_tn(d1); results are the same either way up to
+ * the f32 summation order of the reduction pieces.                                                                              */
+int occ_gemm_tn_pair(const occ_gemm_tn_desc* d0, const occ_gemm_tn_desc* d1, void* stream);
 /* out[n] += alpha * sum_m A[m,n] (bias gradients).                                                   */
 int occ_colsum(const void* A, int a_dtype, const occ_rowmap* a_map, int64_t M, int64_t N, float* out, float alpha, void* stream);   /* A f32 or bf16 */
 
@@ -365,7 +370,7 @@ int occ_conv0_ln_gelu_bwd(const float* wav, const float* w, const float* bias, c
                           int64_t C, int64_t k, int64_t stride, float eps, void* stream);
 /* weight_norm(dim=2) of fairseq's pos_conv: v f32 [O,I,K], g f32 [K] -> bf16 GEMM operands w_fwd [G][O/G][K][I] and (optional)
  * w_bwd [G][I][K][O/G] (taps reversed, for the input gradient), norms f32 [K]; bwd maps a packed-layout weight gradient to dv, dg.
- * scratch (optional, caller-owned): with at least 64*K floats (pack) / (O+1)*K floats (bwd) and 256 % K == 0 the coalesced kernels run
+ * scratch (optional, caller-owned): with at least 512*K floats (pack) / (O+1)*K floats (bwd) and 256 % K == 0 the coalesced kernels run
  * (LDS transposes, fixed-order partial sums); NULL = one workgroup per tap with strided reads.                                   */
 int occ_weight_norm_pack(const float* v, const float* g, void* w_fwd, void* w_bwd, float* norms, int64_t O, int64_t I, int64_t K,
                          int64_t G, float* scratch, int64_t scratch_floats, void* stream);

@@ -69,6 +69,34 @@ def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsu
     check(lib().occ_gemm_tn(ctypes.byref(d), stream_ptr()), "occ_gemm_tn")
 
 
+def _tn_desc_bf16(M, N1, N2, A, a_map, Bm, b_map, C, ldc, colsum_out, ws):
+    d = GemmTnDesc()
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    d.M, d.N1, d.N2 = int(M), int(N1), int(N2)
+    d.A, d.a_map, d.B, d.b_map = _ai(A), a_map, _ai(Bm), b_map
+    d.b_nseg, d.b_seg_len, d.b_seg_stride = 1, int(N2), 0
+    d.C, d.ldc, d.alpha = _ai(C), int(ldc), 1.0
+    d.colsum = _ai(colsum_out)
+    d.a_dtype, d.b_dtype, d.compute = 1, 1, 1
+    return d
+
+
+def gemm_tn_pair(M, first, second):
+    """Two bf16 weight gradients with the same reduction rows in one launch where the library can (occ_gemm_tn_pair); first / second =
+    (N1, N2, A, a_map, B, b_map, C, ldc, colsum_out)."""
+    ws = tn_workspace()
+    d0, d1 = _tn_desc_bf16(M, *first, ws), _tn_desc_bf16(M, *second, ws)
+    from . import ops
+    if ops.PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().occ_gemm_tn_pair(ctypes.byref(d0), ctypes.byref(d1), stream_ptr()), "occ_gemm_tn_pair")
+        e1.record()
+        ops.PROFILE.append(("gemm_bf16", e0, e1))
+        return
+    check(lib().occ_gemm_tn_pair(ctypes.byref(d0), ctypes.byref(d1), stream_ptr()), "occ_gemm_tn_pair")
+
+
 def colsum(A, a_map, M, N, out, alpha=1.0, a_dtype=0):
     """a_dtype: 0 = f32 (default), 1 = bf16; pass a tensor for A to have it inferred."""
     if hasattr(A, "dtype"):

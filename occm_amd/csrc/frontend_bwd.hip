@@ -51,6 +51,30 @@ __global__ __launch_bounds__(256) void transpose_bf16_batch_kernel(const occ_tra
     const occ_transpose_job j = jobs[lo];
     const long long t = b - j.first_tile, tiles_x = (j.cols + 63) / 64;
     const long long r0 = (t / tiles_x) * 64, c0 = (t % tiles_x) * 64;
+    unsigned short* dst = reinterpret_cast<unsigned short*>(j.dst);
+    if (j.src_dtype == OCC_BF16 && r0 + 64 <= j.rows && c0 + 64 <= j.cols && ((j.ld_src | j.ld_dst) & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(j.src) | reinterpret_cast<uintptr_t>(j.dst)) & 7) == 0) {
+        // whole bf16 tile: 8-byte global accesses both ways (a 2-byte access per lane moves 128 B per wave instruction)
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(j.src);
+        const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;                 // 16 lanes x 4 elements = one 64-element row segment; 16 rows per pass
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rr + 16 * i;
+            const uint2 v = *reinterpret_cast<const uint2*>(src + (r0 + r) * j.ld_src + c0 + q * 4);
+            tile[r][q * 4 + 0] = (unsigned short)(v.x & 0xffff); tile[r][q * 4 + 1] = (unsigned short)(v.x >> 16);
+            tile[r][q * 4 + 2] = (unsigned short)(v.y & 0xffff); tile[r][q * 4 + 3] = (unsigned short)(v.y >> 16);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = rr + 16 * i;
+            uint2 v;
+            v.x = (unsigned)tile[q * 4 + 0][c] | ((unsigned)tile[q * 4 + 1][c] << 16);
+            v.y = (unsigned)tile[q * 4 + 2][c] | ((unsigned)tile[q * 4 + 3][c] << 16);
+            *reinterpret_cast<uint2*>(dst + (c0 + c) * j.ld_dst + r0 + q * 4) = v;
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
@@ -63,7 +87,6 @@ __global__ __launch_bounds__(256) void transpose_bf16_batch_kernel(const occ_tra
         tile[ty + 4 * i][tx] = v;
     }
     __syncthreads();
-    unsigned short* dst = reinterpret_cast<unsigned short*>(j.dst);
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const long long c = c0 + ty + 4 * i, r = r0 + tx;
@@ -574,19 +597,21 @@ __global__ __launch_bounds__(256) void wn_sumsq_kernel(const float* __restrict__
     }
 }
 // one workgroup per output channel o: wf[o][k][i] = bf16(v[o][i][k] * g[k] / ||v_k||)
-__global__ __launch_bounds__(256) void wn_pack_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ partial, int S,
-                                                         unsigned short* __restrict__ wf, float* __restrict__ norms, int I, int K) {
+// norms[k] = sqrt(sum of the S partial rows), in row order
+__global__ __launch_bounds__(256) void wn_norms_kernel(const float* __restrict__ partial, int S, float* __restrict__ norms, int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float t = 0.f;
+    for (int j = 0; j < S; ++j) t += partial[(long long)j * K + k];
+    norms[k] = sqrtf(t);
+}
+__global__ __launch_bounds__(256) void wn_pack_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ norms,
+                                                         unsigned short* __restrict__ wf, int I, int K) {
     extern __shared__ float wn_lds[];
     float* sc = wn_lds;                 // [K]
     float* tile = wn_lds + K;           // [I][K + 1]
     const long long o = blockIdx.x;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        float t = 0.f;
-        for (int j = 0; j < S; ++j) t += partial[(long long)j * K + k];
-        const float nrm = sqrtf(t);
-        sc[k] = g[k] / nrm;
-        if (o == 0) norms[k] = nrm;
-    }
+    for (int k = threadIdx.x; k < K; k += 256) sc[k] = g[k] / norms[k];
     for (int idx = threadIdx.x; idx < I * K; idx += 256) { const int i = idx / K, k = idx - i * K; tile[i * (K + 1) + k] = v[(o * I + i) * K + k]; }
     __syncthreads();
     for (int idx = threadIdx.x; idx < I * K; idx += 256) {
@@ -796,11 +821,12 @@ int occ_weight_norm_pack(const float* v, const float* g, void* w_fwd, void* w_bw
                          int64_t scratch_floats, void* stream) {
     OCC_CHECK_ARG(v && g && w_fwd && norms && O >= 1 && I >= 1 && K >= 1 && G >= 1 && O % G == 0, "occ_weight_norm_pack: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t cgn = O / G, S = 64;
+    const int64_t cgn = O / G, S = 512;
     const size_t lds_f = (size_t)(K + I * (K + 1)) * 4, lds_b = (size_t)(K + cgn * (K + 1)) * 4;
     if (scratch && scratch_floats >= S * K && K <= 256 && 256 % K == 0 && lds_f <= 64 * 1024 && lds_b <= 64 * 1024) {
         hipLaunchKernelGGL(wn_sumsq_kernel, dim3((unsigned)S), dim3(256), 0, s, v, scratch, (long long)(O * I), (int)K);
-        hipLaunchKernelGGL(wn_pack_fwd_kernel, dim3((unsigned)O), dim3(256), lds_f, s, v, g, (const float*)scratch, (int)S, (unsigned short*)w_fwd, norms, (int)I, (int)K);
+        hipLaunchKernelGGL(wn_norms_kernel, dim3((unsigned)occ_cdiv(K, 256)), dim3(256), 0, s, (const float*)scratch, (int)S, norms, (int)K);
+        hipLaunchKernelGGL(wn_pack_fwd_kernel, dim3((unsigned)O), dim3(256), lds_f, s, v, g, (const float*)norms, (unsigned short*)w_fwd, (int)I, (int)K);
         if (w_bwd) hipLaunchKernelGGL(wn_pack_bwd_kernel, dim3((unsigned)(G * I)), dim3(256), lds_b, s, v, g, (const float*)norms, (unsigned short*)w_bwd, (int)I, (int)K, (int)cgn);
     } else {
         hipLaunchKernelGGL(weight_norm_pack_kernel, dim3((unsigned)K), dim3(256), 0, s, v, g, (unsigned short*)w_fwd, (unsigned short*)w_bwd, norms, (int)O, (int)I, (int)K, (int)G);

@@ -459,6 +459,9 @@ static void launch_colsum_bf16_vec(const unsigned short* A, const RowMapI& amap,
 // gemm_tn_p8.hip
 int occ_tn_p8_try(long long M, long long N1, long long N2, const void* A, const RowMapI& amap, const void* B, const RowMapI& bmap, float* C, long long ldc,
                   float alpha, void* workspace, long long workspace_bytes, long long max_a_off, long long max_b_off, hipStream_t s);
+int occ_tn_p8_pair_try(long long M, const long long* N1, const long long* N2, const void* const* A, const RowMapI* amap, const void* const* B, const RowMapI* bmap,
+                       float* const* C, const long long* ldc, const float* alpha, void* workspace, long long workspace_bytes, const long long* max_a_off,
+                       const long long* max_b_off, hipStream_t s);
 
 static long long max_row_off(const occ_rowmap& m, long long M) {       // upper bound of the element offset of any row < M
     const long long nb = (M - 1) / m.rows_per_batch;
@@ -468,6 +471,38 @@ static long long max_row_off(const occ_rowmap& m, long long M) {       // upper 
 }
 
 extern "C" {
+
+int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream);
+
+// Two weight gradients of one layer (same reduction rows) in one launch of the eight-phase kernel where both qualify; otherwise one by one.
+int occ_gemm_tn_pair(const occ_gemm_tn_desc* d0, const occ_gemm_tn_desc* d1, void* stream) {
+    OCC_CHECK_ARG(d0 && d1, "occ_gemm_tn_pair: null descriptor");
+    const occ_gemm_tn_desc* d[2] = {d0, d1};
+    bool ok = d0->M == d1->M;
+    for (int p = 0; p < 2 && ok; ++p) {
+        const occ_gemm_tn_desc* q = d[p];
+        ok = q->A && q->B && q->C && q->compute == OCC_BF16 && q->a_dtype == OCC_BF16 && q->b_dtype == OCC_BF16 && q->b_nseg <= 1 && q->ldc >= q->N2 &&
+             q->a_map.rows_per_batch >= 1 && q->b_map.rows_per_batch >= 1 && q->a_map.row_stride % 8 == 0 && q->b_map.row_stride % 8 == 0 &&
+             ((uintptr_t)q->A & 15) == 0 && ((uintptr_t)q->B & 15) == 0;
+    }
+    if (ok) {
+        long long N1[2], N2[2], ldc[2], ma[2], mb[2];
+        const void* A[2]; const void* B[2]; float* C[2]; float alpha[2]; RowMapI am[2], bm[2];
+        for (int p = 0; p < 2; ++p) {
+            N1[p] = d[p]->N1; N2[p] = d[p]->N2; ldc[p] = d[p]->ldc; A[p] = d[p]->A; B[p] = d[p]->B; C[p] = (float*)d[p]->C; alpha[p] = d[p]->alpha;
+            am[p] = to_rowmap(d[p]->a_map); bm[p] = to_rowmap(d[p]->b_map);
+            ma[p] = max_row_off(d[p]->a_map, d[p]->M) + d[p]->N1; mb[p] = max_row_off(d[p]->b_map, d[p]->M) + d[p]->N2;
+        }
+        if (occ_tn_p8_pair_try(d0->M, N1, N2, A, am, B, bm, C, ldc, alpha, d0->workspace, d0->workspace_bytes, ma, mb, (hipStream_t)stream) == 1) {
+            for (int p = 0; p < 2; ++p)
+                if (d[p]->colsum) launch_colsum_bf16_vec((const unsigned short*)d[p]->A, am[p], d[p]->M, d[p]->N1, (float*)d[p]->colsum, d[p]->alpha, (hipStream_t)stream);
+            OCC_LAUNCH_CHECK("occ_gemm_tn_pair");
+            return OCC_OK;
+        }
+    }
+    const int rc = occ_gemm_tn(d0, stream);
+    return rc != OCC_OK ? rc : occ_gemm_tn(d1, stream);
+}
 
 int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
     OCC_CHECK_ARG(d && d->A && d->B && d->C, "occ_gemm_tn: null operand");

@@ -68,13 +68,17 @@ template <int OFF> __device__ __forceinline__ u32x4 frag(unsigned addr) {
     __builtin_amdgcn_s_barrier();                                                                  \
     __builtin_amdgcn_sched_barrier(0);
 
-template <bool PLAIN>
-__global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(const Args a) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 65536];
-    // block -> (tile, piece): the pieces of one tile are neighbours in the XCD-contiguous order (their slabs meet in one L2)
+// XCD-contiguous virtual block id: blocks b, b + 8, ... share an XCD and get a contiguous range of work
+__device__ __forceinline__ int tn_vid() {
     const int total = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q8 = total >> 3, r8 = total & 7;
-    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+
+template <bool PLAIN>
+__device__ __forceinline__ void tn_p8_body(const Args& a, const int vid) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 65536];
+    // block -> (tile, piece): the pieces of one tile are neighbours in the XCD-contiguous order (their slabs meet in one L2)
     const int piece = vid % a.S, tile = vid / a.S;
     const int tx = tile % a.t1, ty = tile / a.t1;
     const long long n1_0 = (long long)tx * 256, n2_0 = (long long)ty * 256;
@@ -244,6 +248,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(const Args a) {
     }
 }
 
+template <bool PLAIN>
+__global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(const Args a) { tn_p8_body<PLAIN>(a, tn_vid()); }
+
+// Two products of one layer in one launch (out-proj with qkv, fc2 with fc1: same reduction length, different operands).  Each launch has
+// one workgroup per CU and leaves 64 MB of f32 slabs however few tiles it has, so two launches of 16 + 48 tiles cut their reductions 16
+// and 5 ways where one launch of 64 tiles cuts them 4 ways: half the slab traffic, K loops four times as long for the small product.
+struct ArgsPair { Args v[2]; int wgs0; };
+template <bool PLAIN>
+__global__ __launch_bounds__(512, 2) void gemm_tn_p8_pair_kernel(const ArgsPair ap) {
+    const int vid = tn_vid();
+    const int second = vid >= ap.wgs0 ? 1 : 0;          // wave-uniform: the argument block is read from the kernel-argument segment
+    tn_p8_body<PLAIN>(ap.v[second], vid - (second ? ap.wgs0 : 0));
+}
+
 // C += alpha * sum over pieces of the slabs (reduce_kernel mode): thread = one f32x4 of one (tile, wave, accumulator, lane) slot,
 // i.e. the slab layout itself (coalesced 1 KiB reads per wave and piece), C addressed as the main kernel's epilogue does.
 __global__ __launch_bounds__(256) void tn_p8_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, long long ldc, float alpha, int S, int t1) {
@@ -259,7 +277,67 @@ __global__ __launch_bounds__(256) void tn_p8_reduce_kernel(const float* __restri
     *cp = *cp + v * alpha;
 }
 
+// the same for a pair of products sharing S: blockIdx.y < tiles0 -> first product
+__global__ __launch_bounds__(256) void tn_p8_reduce_pair_kernel(const float* __restrict__ slabs0, float* __restrict__ C0, long long ldc0, int t1_0, int tiles0,
+                                                               const float* __restrict__ slabs1, float* __restrict__ C1, long long ldc1, int t1_1, float alpha0,
+                                                               float alpha1, int S) {
+    const bool second = (int)blockIdx.y >= tiles0;
+    const int tile = second ? blockIdx.y - tiles0 : blockIdx.y;
+    const float* slabs = second ? slabs1 : slabs0;
+    float* C = second ? C1 : C0;
+    const long long ldc = second ? ldc1 : ldc0;
+    const int t1 = second ? t1_1 : t1_0;
+    const float alpha = second ? alpha1 : alpha0;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int lane = slot & 63, k = (slot >> 6) & 31, wave = slot >> 11;
+    const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + (long long)tile * S * 16384 + slot;
+    f32x4 v = p[0];
+    for (int s = 1; s < S; ++s) v += p[(long long)s * 16384];
+    const int i = k >> 3, j = k & 7, wr = wave >> 2, wc = wave & 3, fr = lane & 15, g = lane >> 4;
+    const long long n1 = (long long)(tile % t1) * 256 + wr * 128 + j * 16 + fr, n2 = (long long)(tile / t1) * 256 + wc * 64 + i * 16 + g * 4;
+    f32x4* cp = reinterpret_cast<f32x4*>(C + n1 * ldc + n2);
+    *cp = *cp + v * alpha;
+}
+
 }  // namespace occ_tn_p8
+
+// Two products in one launch.  Returns 1 when launched, 0 when the pair is not eligible (the caller runs them one by one).
+// Requirements on top of occ_tn_p8_try's: the same M (a multiple of 64), plain row maps on all four operands, a workspace for the slabs.
+int occ_tn_p8_pair_try(long long M, const long long* N1, const long long* N2, const void* const* A, const RowMapI* amap, const void* const* B, const RowMapI* bmap,
+                       float* const* C, const long long* ldc, const float* alpha, void* workspace, long long workspace_bytes, const long long* max_a_off,
+                       const long long* max_b_off, hipStream_t s) {
+    using namespace occ_tn_p8;
+    static const int en = getenv("OCC_TN_P8") ? atoi(getenv("OCC_TN_P8")) : 1;
+    static const int pair_en = getenv("OCC_TN_PAIR") ? atoi(getenv("OCC_TN_PAIR")) : 1;
+    if (!en || !pair_en || M < 1024 || M % 64 || !workspace || ((uintptr_t)workspace & 15)) return 0;
+    ArgsPair ap;
+    long long tiles[2];
+    for (int p = 0; p < 2; ++p) {
+        if (N1[p] % 256 || N2[p] % 256 || ldc[p] % 4 || ((uintptr_t)C[p] & 15)) return 0;
+        if (max_a_off[p] * 2 >= (1ll << 32) || max_b_off[p] * 2 >= (1ll << 32)) return 0;
+        if (!(amap[p].rpl == 0 && bmap[p].rpl == 0 && amap[p].rpb >= M && bmap[p].rpb >= M)) return 0;
+        Args& a = ap.v[p];
+        a.N1 = N1[p]; a.N2 = N2[p]; a.A = (const char*)A[p]; a.amap = amap[p]; a.B = (const char*)B[p]; a.bmap = bmap[p]; a.C = C[p]; a.ldc = ldc[p]; a.alpha = alpha[p];
+        a.t1 = (int)(N1[p] / 256); a.t2 = (int)(N2[p] / 256);
+        a.nt = (int)(M / 64);
+        a.plain = 1;
+        tiles[p] = (long long)a.t1 * a.t2;
+    }
+    static int cus = 0;
+    if (!cus) { int dev = 0, v = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }
+    const long long T = tiles[0] + tiles[1];
+    long long S = cus / T;
+    if (S > ap.v[0].nt / 8) S = ap.v[0].nt / 8;
+    if (S < 2 || T * S * 262144 > workspace_bytes) return 0;          // (a single piece has no slabs: nothing to gain over two launches)
+    for (int p = 0; p < 2; ++p) ap.v[p].S = (int)S;
+    ap.v[0].slabs = (float*)workspace;
+    ap.v[1].slabs = (float*)workspace + tiles[0] * S * 65536;
+    ap.wgs0 = (int)(tiles[0] * S);
+    hipLaunchKernelGGL(gemm_tn_p8_pair_kernel<true>, dim3((unsigned)(T * S)), dim3(512), 0, s, ap);
+    hipLaunchKernelGGL(tn_p8_reduce_pair_kernel, dim3(64, (unsigned)T), dim3(256), 0, s, ap.v[0].slabs, ap.v[0].C, ap.v[0].ldc, ap.v[0].t1, (int)tiles[0], ap.v[1].slabs,
+                       ap.v[1].C, ap.v[1].ldc, ap.v[1].t1, ap.v[0].alpha, ap.v[1].alpha, (int)S);
+    return 1;
+}
 
 // Host side.  Returns 1 when the launch was made, 0 when the problem is not this kernel's (the caller falls back), < 0 on error.
 // Covers rows [0, rows64) with rows64 = M - M % 64; the caller adds the last M % 64 rows with the small-tile kernel.

@@ -706,6 +706,11 @@ class XlsrFineTuner(XlsrFrontend):
         K.gemm_tn(M, N, Kd, dy, rowmap(M, 0, N), x, rowmap(M, 0, Kd), self.mg[gname], Kd, colsum_out=self.mg[bias_name], a_bf16=True, b_bf16=True,
                   bf16_mfma=True)
 
+    def _wgrad_pair(self, M, a, b):
+        """Two weight (+ bias) gradients of one layer, (dy, x, N, Kd, gname, bias_name) each, in one launch (occ_gemm_tn_pair)."""
+        from .. import backend_ops as K
+        K.gemm_tn_pair(M, *[(N, Kd, dy, rowmap(M, 0, N), x, rowmap(M, 0, Kd), self.mg[g], Kd, self.mg[bn]) for dy, x, N, Kd, g, bn in (a, b)])
+
     def layer_grad_range(self, i):
         """[lo, hi) of transformer layer i's gradients in the flat buffer self.G (its twelve tensors are contiguous)."""
         lo = self.tslots["l%d.qkv.w" % i][0]
@@ -738,21 +743,20 @@ class XlsrFineTuner(XlsrFrontend):
             dyb = dxb
             if p_res > 0:
                 dyb = tr["dyb"]; self._drop_bwd("l%d.d3" % i, dxb, dyb, p_res)
-            self._wgrad(dyb, s["f"], D, Fd, M, "l%d.fc2.w" % i, "l%d.fc2.b" % i)
             self._dgrad(i, "fc2.w", dyb, "g_fc2", M, Fd, D, tr["du"], act=ACT_GELU_GRAD, aux=s["u"])
             if p_act > 0:                                        # (elementwise factors commute: mask after GELU')
                 self._drop_bwd("l%d.act" % i, tr["du"], tr["du"], p_act)
-            self._wgrad(tr["du"], s["h2"], Fd, D, M, "l%d.fc1.w" % i, "l%d.fc1.b" % i)
+            # both FFN weight gradients in one launch (dyb is not rewritten before the LayerNorm backward below)
+            self._wgrad_pair(M, (dyb, s["f"], D, Fd, "l%d.fc2.w" % i, "l%d.fc2.b" % i), (tr["du"], s["h2"], Fd, D, "l%d.fc1.w" % i, "l%d.fc1.b" % i))
             self._dgrad(i, "fc1.w", tr["du"], "g_fc1", M, D, Fd, tr["dh"])
             ops.layernorm_bwd(tr["dh"], s["x_mid"], w["l%d.ln2.g" % i], dx, dx, self.mg["l%d.ln2.g" % i], self.mg["l%d.ln2.b" % i], dx_bf16=dxb)
             # ---- attention: x_mid = x_in + dropout1(out_proj(attn(qkv(LN1(x_in)))))
             dyb = dxb
             if p_res > 0:
                 dyb = tr["dyb"]; self._drop_bwd("l%d.d1" % i, dxb, dyb, p_res)
-            self._wgrad(dyb, s["att"], D, D, M, "l%d.o.w" % i, "l%d.o.b" % i)
             self._dgrad(i, "o.w", dyb, "g_o", M, D, D, tr["da"])
             ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
-            self._wgrad(tr["dqkv"], s["h1"], 3 * D, D, M, "l%d.qkv.w" % i, "l%d.qkv.b" % i)
+            self._wgrad_pair(M, (dyb, s["att"], D, D, "l%d.o.w" % i, "l%d.o.b" % i), (tr["dqkv"], s["h1"], 3 * D, D, "l%d.qkv.w" % i, "l%d.qkv.b" % i))
             self._dgrad(i, "qkv.w", tr["dqkv"], "g_qkv", M, D, 3 * D, tr["dh"])
             ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i], dx_bf16=dxb)
             if grad_ready is not None:

@@ -73,3 +73,25 @@ def test_tn_p8_random_data_and_race_screen():
                 first[i] = C.clone()
             else:
                 assert torch.equal(C, first[i]), (it, M, N1, N2)         # fixed summation order: bit-reproducible
+
+
+@pytest.mark.parametrize("M,shapes", [(12736, ((1024, 1024), (3072, 1024))), (12736, ((1024, 4096), (4096, 1024))), (2048, ((256, 256), (512, 256))),
+                                      (1000, ((256, 256), (256, 512)))])
+def test_tn_p8_pair_launch_exact(M, shapes):
+    """occ_gemm_tn_pair: two weight (+ bias) gradients with the same reduction rows in one launch (out-proj with qkv, fc2 with fc1 at bs 64;
+    a small pair; a row count that is not a multiple of 64, which runs as two single launches).  Integer operands: exact, with
+    accumulation onto non-zero C and bias buffers."""
+    from occm_amd import backend_ops as K
+    ops_in, refs, outs = [], [], []
+    for p, (N1, N2) in enumerate(shapes):
+        a, b = _ints(M, N1, 10 + p), _ints(M, N2, 20 + p)
+        c0, s0 = _ints(N1, N2, 30 + p, -50, 50), _ints(1, N1, 40 + p, -9, 9)[0]
+        C, s = c0.clone().cuda(), s0.clone().cuda()
+        ad, bd = a.bfloat16().cuda(), b.bfloat16().cuda()
+        ops_in.append((N1, N2, ad, K.full(M, N1), bd, K.full(M, N2), C, N2, s))
+        refs.append((c0.double() + a.double().T @ b.double(), s0.double() + a.double().sum(0)))
+        outs.append((C, s))
+    K.gemm_tn_pair(M, ops_in[0], ops_in[1])
+    for (C, s), (rc, rs) in zip(outs, refs):
+        assert torch.equal(C.cpu().double(), rc), float((C.cpu().double() - rc).abs().max())
+        assert torch.equal(s.cpu().double(), rs)
