@@ -241,7 +241,7 @@ def pmc_traffic(tag):
         pm = json.load(open(path))
         if pm.get("gemm_src_sha16") != gemm_source_sha():
             return None, "profiles/%s is from other GEMM sources (%s): not reported" % (os.path.basename(path), pm.get("gemm_src_sha16"))
-        ks = [v for k, v in pm["kernels"].items() if ("gemm_" in k and "bf16" in k) or "gemm_tn_p8" in k or "gemm_tn_dma" in k]      # (not the slab reduce kernel)
+        ks = [v for k, v in pm["kernels"].items() if ("gemm_" in k and "bf16" in k) or "gemm_p8_kernel<0" in k or "gemm_tn_p8" in k or "gemm_tn_dma" in k]      # (bf16 forms; not the slab reduce kernels)
         n = sum(v["launches"] for v in ks)
         return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks) / max(n, 1)), \
             "profiles/%s (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE, launch-weighted over the bf16 GEMM kernels)" % os.path.basename(path)
