@@ -42,7 +42,7 @@ def parse_args(argv=None):
     ap.add_argument("--xlsr", default="300m", choices=["300m", "1b"], help="1b: XLS-R-1B geometry (48 layers, d 1280, heads of 80), not the headline")
     ap.add_argument("--backend", default="aasist", choices=["aasist", "senet"], help="senet: SE-ResNet34 on the XLS-R features (not the headline)")
     ap.add_argument("--no-graph", action="store_true", help="--frozen only: do not replay the frozen front-end from a HIP graph")
-    ap.add_argument("--no-overlap", action="store_true", help="--frozen only: no side-stream prefetch of the next batch's features")
+    ap.add_argument("--no-overlap", action="store_true", help="no side-stream prefetch of the next batch's data stage (frozen: RawBoost + features; fine-tuned: RawBoost)")
     ap.add_argument("--fp8", action="store_true", help="not the headline: forward / input-gradient GEMMs of the transformer layers on the fp8 MFMA path (e4m3 / e5m2, "
                     "delayed per-tensor scaling), as BASELINE configs[4] asks for XLS-R-1B; weight gradients stay bf16")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous only (gloo, no GPU call): every rank reports world size and its shard of the "
@@ -311,9 +311,10 @@ def main():
         fe.forward = replay_forward
 
     # Every step does the whole path on one batch.  With the frozen front-end the trainer software-pipelines two steps: the data
-    # stage (RawBoost + XLS-R features) of step i+1 runs on a side stream while the back-end of step i trains; the timed region
-    # still contains exactly `steps` data stages and `steps` back-end updates (the first data stage is not overlapped).
-    overlap = not args.no_overlap and not finetune
+    # stage (RawBoost + XLS-R features) of step i+1 runs on a side stream while the back-end of step i trains; when the front-end is
+    # trained only RawBoost of step i+1 can run ahead (under step i's back-end section).  Either way the timed region still contains
+    # exactly `steps` data stages and `steps` updates (the first data stage is not overlapped).
+    overlap = not args.no_overlap
     for i in range(args.warmup):
         trainer.step(wav, labels, next_wav=wav if overlap and i + 1 < args.warmup else None)
     parallel.barrier(); torch.cuda.synchronize()

@@ -335,3 +335,39 @@ def test_weight_norm_pack_and_backward_coalesced_kernels(O, I, K, G):
         torch.testing.assert_close(dg.cpu() - 1, g.grad, rtol=1e-4, atol=1e-4 * float(g.grad.abs().max()))
         res.append((wf, wb))
     assert float((res[0][0].float() - res[1][0].float()).abs().max()) <= 1e-2 * float(res[1][0].float().abs().max())
+
+
+def test_finetune_trainer_rawboost_prefetch_gives_the_sequential_samples():
+    """OcTrainer with a trained front-end and on-GPU RawBoost: passing the next batch lets its augmentation run on a side stream under
+    the current step's back-end section.  The waveform every step's front-end sees must be bit-identical to the sequential order's
+    (same (seed, step) keys), and the first step's losses identical."""
+    from occm_amd.models import xlsr
+    from occm_amd.models.sslassist import AModel
+    from occm_amd.trainer import OcTrainer
+    cfg = xlsr.XlsrConfig(dim=256, ffn=512, heads=4, layers=1)
+    g = torch.Generator().manual_seed(1)
+    wavs = [(0.1 * torch.randn(12, 16000, generator=g)).cuda() for _ in range(4)]
+    labels = (torch.arange(12) >= 6).long().cuda()
+
+    def run(pipelined):
+        model = AModel(None, "cuda", ssl_cfg=cfg, seed=0, synthetic_ssl=True, finetune_ssl="full")
+        model.train()
+        tr = OcTrainer(model, lr=1e-5, w_compact=0.1, w_descr=0.9, train_frontend=True, rawboost_algo=5, seed=3, group_size=12)
+        seen, fwd = [], tr.fe.forward_train
+
+        def spy(w):
+            seen.append(w.clone())
+            return fwd(w)
+        tr.fe.forward_train = spy
+        out = []
+        for i, w in enumerate(wavs):
+            lc, ld = tr.step(w, labels, next_wav=wavs[i + 1] if pipelined and i + 1 < len(wavs) else None)
+            out.append((float(lc), float(ld)))
+        return out, seen
+
+    seq, w_seq = run(False)
+    pip, w_pip = run(True)
+    assert len(w_seq) == len(w_pip) == len(wavs)
+    for a, b in zip(w_seq, w_pip):
+        assert torch.equal(a, b) and not torch.equal(a, wavs[0])             # augmented, and the same samples either way
+    assert seq[0] == pip[0]
