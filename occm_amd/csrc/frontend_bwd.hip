@@ -439,11 +439,11 @@ __global__ void gelu_bwd_rows_kernel(const float* __restrict__ dy, const unsigne
 constexpr int C0B_FRAMES = 256, C0B_MAXK = 16;   // C0B_MAXK: largest supported tap count
 // KT = compile-time tap count held in registers (weights + their gradients: 16 * KT VGPRs per lane); KT = 10 is XLS-R's first conv.
 template <typename TD, int KT>
-__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w, const float* __restrict__ bias,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, const TD* __restrict__ dact,
                                                        float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                        int L, int Tout, int k, int stride, float eps) {
-    extern __shared__ __attribute__((aligned(16))) float smp[];          // samples | reduction scratch [3][512*(k+3)]
+    extern __shared__ __attribute__((aligned(16))) float smp[];          // samples | reduction scratch [512*(k+3)]
     const int b = blockIdx.y, f0 = blockIdx.x * C0B_FRAMES;
     const int nsamp = (C0B_FRAMES - 1) * stride + k;
     float* red = smp + ((nsamp + 3) & ~3);
@@ -451,11 +451,15 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < nsamp; i += 256) { const int g = f0 * stride + i; smp[i] = g < L ? wb[g] : 0.f; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = lane * 8;
-    float wr[8][KT], br[8], gr[8], ber[8];
+    // conv bias / LayerNorm gamma / beta of the lane's channels are read from LDS at each use: 24 registers that decide whether two waves
+    // fit a SIMD without spilling (wr + gw alone are 160)
+    __shared__ float cst[3][512];
+    for (int i = threadIdx.x; i < 512; i += 256) { cst[0][i] = bias[i]; cst[1][i] = gamma[i]; cst[2][i] = beta[i]; }
+    const float* br = cst[0] + c0; const float* gr = cst[1] + c0; const float* ber = cst[2] + c0;
+    float wr[8][KT];
     float gw[8][KT], gb[8], gg[8], gbe[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        br[e] = bias[c0 + e]; gr[e] = gamma[c0 + e]; ber[e] = beta[c0 + e];
         gb[e] = 0.f; gg[e] = 0.f; gbe[e] = 0.f;
 #pragma unroll
         for (int t = 0; t < KT; ++t) { wr[e][t] = t < k ? w[(size_t)(c0 + e) * k + t] : 0.f; gw[e][t] = 0.f; }
@@ -501,33 +505,38 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
             for (int t = 0; t < KT; ++t) gw[e][t] = fmaf(dp, xs[t], gw[e][t]);
         }
     }
-    // reduce over the 4 waves: layout per wave [512][k+3] = (dw[k], dbias, dgamma, dbeta)
+    // reduce over the 4 waves through ONE [512][k+3] = (dw[k], dbias, dgamma, dbeta) scratch, wave after wave (three separate images made
+    // the workgroup 85 KB of LDS: one workgroup = one wave per SIMD on a kernel that is a chain of dependent wave reductions)
     const int rs = k + 3;
-    __syncthreads();
-    if (wave > 0) {
-        float* r = red + (size_t)(wave - 1) * 512 * rs;
+    for (int w2 = 1; w2 < 4; ++w2) {
+        __syncthreads();
+        if (wave == w2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 8; ++e) {
+                float* r = red + (c0 + e) * rs;
 #pragma unroll
-            for (int t = 0; t < KT; ++t) if (t < k) r[(c0 + e) * rs + t] = gw[e][t];      // static index: a run-time index would push gw to scratch
-            r[(c0 + e) * rs + k] = gb[e]; r[(c0 + e) * rs + k + 1] = gg[e]; r[(c0 + e) * rs + k + 2] = gbe[e];
+                for (int t = 0; t < KT; ++t) if (t < k) r[t] = gw[e][t];      // static index: a run-time index would push gw to scratch
+                r[k] = gb[e]; r[k + 1] = gg[e]; r[k + 2] = gbe[e];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float* r = red + (c0 + e) * rs;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) if (t < k) gw[e][t] += r[t];
+                gb[e] += r[k]; gg[e] += r[k + 1]; gbe[e] += r[k + 2];
+            }
         }
     }
-    __syncthreads();
     if (wave == 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                if (t >= k) continue;
-                float v = gw[e][t];
-                for (int w2 = 0; w2 < 3; ++w2) v += red[(size_t)w2 * 512 * rs + c * rs + t];
-                atomicAdd(dw + (size_t)c * k + t, v);
-            }
-            float v0 = gb[e], v1 = gg[e], v2 = gbe[e];
-            for (int w2 = 0; w2 < 3; ++w2) { const float* r = red + (size_t)w2 * 512 * rs + c * rs; v0 += r[k]; v1 += r[k + 1]; v2 += r[k + 2]; }
-            atomicAdd(dbias + c, v0); atomicAdd(dgamma + c, v1); atomicAdd(dbeta + c, v2);
+            for (int t = 0; t < KT; ++t) if (t < k) atomicAdd(dw + (size_t)c * k + t, gw[e][t]);
+            atomicAdd(dbias + c, gb[e]); atomicAdd(dgamma + c, gg[e]); atomicAdd(dbeta + c, gbe[e]);
         }
     }
 }
@@ -801,7 +810,7 @@ int occ_conv0_ln_gelu_bwd(const float* wav, const float* w, const float* bias, c
                   "occ_conv0_ln_gelu_bwd: bad shape");
     OCC_CHECK_ARG(dact_dtype == OCC_F32 || dact_dtype == OCC_BF16, "occ_conv0_ln_gelu_bwd: dact must be f32 or bf16");
     const int nsamp = (int)((C0B_FRAMES - 1) * stride + k);
-    const size_t shm = ((size_t)((nsamp + 3) & ~3) + (size_t)3 * 512 * (k + 3)) * sizeof(float);
+    const size_t shm = ((size_t)((nsamp + 3) & ~3) + (size_t)512 * (k + 3)) * sizeof(float);
     const dim3 grid((unsigned)occ_cdiv(Tout, C0B_FRAMES), (unsigned)B), block(256);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
