@@ -151,6 +151,8 @@ def gemm_bytes_per_step(cfg, L, B, finetune):
         per += m * kk * 2 + nn * kk * 2 + m * nn * (ce + re)
         if finetune:
             per += (m * nn * 2 + nn * kk * 2 + m * kk * 2) + (m * nn * 2 + m * kk * 2 + 2 * nn * kk * 4)
+    if finetune:
+        per += 2 * M * f * 2          # fc1's epilogue also stores the bf16 pre-activation; fc2's input-gradient epilogue reads it (GELU')
     return tot + n * per
 
 
