@@ -134,7 +134,12 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         dl += __uint_as_float(x[e] << 16) * __uint_as_float(y[e] << 16) + __uint_as_float(x[e] & 0xffff0000u) * __uint_as_float(y[e] & 0xffff0000u);
-                    atomicAdd(&dlt_s[buf * 32 + r], dl);
+                    if (CH == 8) {                     // a row's 8 chunks sit in 8 consecutive lanes: three shuffle steps instead of 8 same-address LDS atomics
+                        dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
+                        if (c == 0) dlt_s[buf * 32 + r] = dl;
+                    } else {
+                        atomicAdd(&dlt_s[buf * 32 + r], dl);
+                    }
                 }
             }
         }
