@@ -167,6 +167,13 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
         if (tid < 32) dlt_s[(buf ^ 1) * 32 + tid] = 0.f;            // the other buffer's delta is re-accumulated by the next commit
         const unsigned qs0 = lds0 + (unsigned)(Qs - sm) + buf * 32 * ROWB, ds0 = lds0 + (unsigned)(dOs - sm) + buf * 32 * ROWB;
         unsigned pp[2][4], ds[2][4];                   // [key tile][packed bf16 pairs]: slots j < 4 from q-tile 0, j >= 4 from q-tile 1
+        float lq[2][4], dq_[2][4];                     // lse / delta of the lane's eight query rows: read once per step, not once per key tile
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + buf * 32 + qt * 16 + g * 4), d4 = *reinterpret_cast<const f32x4*>(dlt_s + buf * 32 + qt * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { lq[qt][r] = l4[r]; dq_[qt][r] = d4[r]; }
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int tile = wave + 8 * kk;
@@ -186,9 +193,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ql = qt * 16 + g * 4 + r;
-                    const float p = key < nkeys ? __builtin_amdgcn_exp2f(sacc[r] * c2 - lse_s[buf * 32 + ql]) : 0.f;
+                    const float p = key < nkeys ? __builtin_amdgcn_exp2f(sacc[r] * c2 - lq[qt][r]) : 0.f;
                     pv[qt][r] = p;
-                    dsv[qt][r] = p * (dpacc[r] - dlt_s[buf * 32 + ql]);
+                    dsv[qt][r] = p * (dpacc[r] - dq_[qt][r]);
                     dSs[ql * AB_DS_STRIDE + key] = f32_to_bf16_bits(dsv[qt][r]);
                 }
             }
