@@ -439,7 +439,7 @@ __global__ void gelu_bwd_rows_kernel(const float* __restrict__ dy, const unsigne
 constexpr int C0B_FRAMES = 256, C0B_MAXK = 16;   // C0B_MAXK: largest supported tap count
 // KT = compile-time tap count held in registers (weights + their gradients: 16 * KT VGPRs per lane); KT = 10 is XLS-R's first conv.
 template <typename TD, int KT>
-__global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, KT <= 10 ? 2 : 1) void conv0_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w, const float* __restrict__ bias,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, const TD* __restrict__ dact,
                                                        float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                        int L, int Tout, int k, int stride, float eps) {
