@@ -331,8 +331,13 @@ def main():
     # ---- roofline of the dominant kernel family (bf16 MFMA GEMM): algorithmic FLOPs / launch time measured with HIP events on the
     # launch stream, in extra untimed steps of the same workload ----
     roof = None
+    nprof = 2
+    if finetune and rank != 0:
+        # the extra steps contain the gradient all-reduce: every rank takes them, only rank 0 times its launches
+        for _ in range(nprof):
+            trainer.step(wav, labels)
+        torch.cuda.synchronize()
     if rank == 0:
-        nprof = 2
         if graph is not None:
             fe.forward = orig_forward
         ops.PROFILE = []

@@ -201,3 +201,22 @@ def test_finetune_300m_step_gradients_match_oracle_autograd_and_bs64_is_linear(o
     for k in CHECKED:
         if float(pr[k].grad.norm()) / pr[k].grad.numel() ** 0.5 >= 1e-2 * gscale:
             _grad_check(g64[k], g4[k].cpu(), "bs64 e2e " + k, cos_min=0.8, rel_max=1.0)
+
+
+def test_bench_two_ranks_over_gloo_on_one_gpu_complete_and_report_two_gpus(tmp_path):
+    """Rehearsal of the multi-rank bench path on the one-GPU box: two ranks (gloo, sharing the card) run warm-up, timed and the extra
+    roofline-profiling steps -- every one of which contains the gradient all-reduce -- and rank 0 prints one line with n_gpus = 2.
+    (A profiling step taken by rank 0 alone leaves it waiting in the all-reduce for peers that have already left.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OCC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--bs", "12", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 24 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["roofline"]["achieved"] > 0
