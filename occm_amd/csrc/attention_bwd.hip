@@ -55,8 +55,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
     unsigned char* Kimg = sm;                                        // [256][ROWB]
     unsigned char* Qs = Kimg + AB_KEYS * ROWB;                       // [2][32][ROWB]
     unsigned char* dOs = Qs + 2 * 32 * ROWB;                         // [2][32][ROWB]
-    unsigned short* dSs = reinterpret_cast<unsigned short*>(dOs + 2 * 32 * ROWB);       // [32][AB_DS_STRIDE]
-    float* lse_s = reinterpret_cast<float*>(dSs + 32 * AB_DS_STRIDE);                   // [2][32]
+    unsigned short* dSs0 = reinterpret_cast<unsigned short*>(dOs + 2 * 32 * ROWB);      // [2][32][AB_DS_STRIDE]: step st writes buffer st & 1
+    float* lse_s = reinterpret_cast<float*>(dSs0 + 2 * 32 * AB_DS_STRIDE);              // [2][32]
     float* dlt_s = lse_s + 64;                                                          // [2][32]
     const int D = H * HD;
     const int bh = blockIdx.x, b = bh / H, h = bh % H, kb = blockIdx.y;
@@ -153,18 +153,65 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
     }
     if (tid < 64) dlt_s[tid] = 0.f;
     // dS columns of key tiles that are not in use are never written but can be read by the last 32-key step of dQ (against zero K rows)
-    for (int idx = tid; idx < 32 * AB_DS_STRIDE / 8; idx += 512) reinterpret_cast<uint4*>(dSs)[idx] = make_uint4(0, 0, 0, 0);
+    for (int idx = tid; idx < 2 * 32 * AB_DS_STRIDE / 8; idx += 512) reinterpret_cast<uint4*>(dSs0)[idx] = make_uint4(0, 0, 0, 0);
     prefetch(0);
     __syncthreads();
     commit(0);
     const int nstep = (Tn + 31) >> 5;
     // transposing-read lane constants: lane (g, q4 = fr >> 2, p4 = lane & 3) supplies row 4g + q4 of a 16-row group, 8 bytes at p4*8 of a 32-byte block
     const int q4 = fr >> 2, p4 = lane & 3;
+    // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q] of one step: 2 q tiles x DT d tiles, dealt round-robin to the 8 waves.  It runs one
+    // step late (after the barrier that opens the next step, from the other dS buffer), so a step has ONE workgroup barrier: while some
+    // waves add up dQ of step st-1, others are already multiplying S / dP of step st.
+    auto dq_phase = [&](const int q0, const unsigned short* dSs) {
+        for (int pr = wave; pr < 2 * DT; pr += 8) {
+            const int qt = pr / DT, dt = pr - qt * DT;
+            f32x4 qacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int nks = (nkeys + 31) >> 5;
+            for (int ks0 = 0; ks0 < nks; ks0 += 4) {   // four 32-key steps per wait (steps beyond the block read zero K rows: harmless)
+                u32x2 kr[4][2]; uint2 sr[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = ks0 + u < 8 ? ks0 + u : 7;
+                    const int r0 = ks * 32 + 4 * g + q4;
+                    unsigned offa, offb;
+                    if (C::SWZ) { offa = (unsigned)(r0 * 128 + ((dt ^ ((r0 >> 1) & 3)) << 5) + p4 * 8); offb = (unsigned)((r0 + 16) * 128 + ((dt ^ (((r0 + 16) >> 1) & 3)) << 5) + p4 * 8); }
+                    else { offa = (unsigned)(r0 * ROWB + dt * 32 + p4 * 8); offb = offa + 16 * ROWB; }
+                    kr[u][0] = ab_tr_read(lds0 + offa); kr[u][1] = ab_tr_read(lds0 + offb);
+                    sr[u][0] = *reinterpret_cast<const uint2*>(dSs + (qt * 16 + fr) * AB_DS_STRIDE + ks * 32 + 4 * g);
+                    sr[u][1] = *reinterpret_cast<const uint2*>(dSs + (qt * 16 + fr) * AB_DS_STRIDE + ks * 32 + 16 + 4 * g);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ks0 + u >= nks) continue;
+                    const u32x4 ka = (u32x4){kr[u][0][0], kr[u][0][1], kr[u][1][0], kr[u][1][1]}, sbv = (u32x4){sr[u][0].x, sr[u][0].y, sr[u][1].x, sr[u][1].y};
+                    qacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, sbv), qacc, 0, 0, 0);
+                }
+            }
+            const int q = q0 + qt * 16 + fr;           // D rows = d (4g + e), column = query fr
+            if (q < Tn) {
+                if (gridDim.y == 1) {
+                    uint2 ov;
+                    ov.x = (unsigned)f32_to_bf16_bits(qacc[0] * scale) | ((unsigned)f32_to_bf16_bits(qacc[1] * scale) << 16);
+                    ov.y = (unsigned)f32_to_bf16_bits(qacc[2] * scale) | ((unsigned)f32_to_bf16_bits(qacc[3] * scale) << 16);
+                    *reinterpret_cast<uint2*>(dqkv + ((size_t)b * Tn + q) * ld_qkv + (size_t)h * HD + dt * 16 + g * 4) = ov;
+                } else {
+                    float* ap = dq_accum + ((size_t)b * Tn + q) * D + (size_t)h * HD + dt * 16 + g * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(ap + e, qacc[e] * scale);
+                }
+            }
+        }
+    };
     for (int st = 0; st < nstep; ++st) {
         const int q0 = st * 32, buf = st & 1;
+        unsigned short* dSs = dSs0 + buf * 32 * AB_DS_STRIDE;
         if (st + 1 < nstep) prefetch(q0 + 32);
-        __syncthreads();                               // slice `buf` (Q, dO, lse, delta) is complete; the previous step's dS readers are done
-        if (tid < 32) dlt_s[(buf ^ 1) * 32 + tid] = 0.f;            // the other buffer's delta is re-accumulated by the next commit
+        __syncthreads();                               // slice `buf` (Q, dO, lse, delta) and the previous step's dS are complete
+        if (CH != 8 && tid < 32) dlt_s[(buf ^ 1) * 32 + tid] = 0.f;  // (atomics form only) the other buffer's delta is re-accumulated by the next commit
+        if (st > 0) dq_phase(q0 - 32, dSs0 + (buf ^ 1) * 32 * AB_DS_STRIDE);
         const unsigned qs0 = lds0 + (unsigned)(Qs - sm) + buf * 32 * ROWB, ds0 = lds0 + (unsigned)(dOs - sm) + buf * 32 * ROWB;
         unsigned pp[2][4], ds[2][4];                   // [key tile][packed bf16 pairs]: slots j < 4 from q-tile 0, j >= 4 from q-tile 1
         float lq[2][4], dq_[2][4];                     // lse / delta of the lane's eight query rows: read once per step, not once per key tile
@@ -233,51 +280,13 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
                 }
             }
         }
-        __syncthreads();                               // dS of every key tile in use is in LDS
-        if (st + 1 < nstep) commit(buf ^ 1);           // next slice: its buffer was last read in step st-1
-        // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]: 2 q tiles x DT d tiles, dealt round-robin to the 8 waves
-        for (int pr = wave; pr < 2 * DT; pr += 8) {
-            const int qt = pr / DT, dt = pr - qt * DT;
-            f32x4 qacc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int nks = (nkeys + 31) >> 5;
-            for (int ks0 = 0; ks0 < nks; ks0 += 4) {   // four 32-key steps per wait (steps beyond the block read zero K rows: harmless)
-                u32x2 kr[4][2]; uint2 sr[4][2];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ks = ks0 + u < 8 ? ks0 + u : 7;
-                    const int r0 = ks * 32 + 4 * g + q4;
-                    unsigned offa, offb;
-                    if (C::SWZ) { offa = (unsigned)(r0 * 128 + ((dt ^ ((r0 >> 1) & 3)) << 5) + p4 * 8); offb = (unsigned)((r0 + 16) * 128 + ((dt ^ (((r0 + 16) >> 1) & 3)) << 5) + p4 * 8); }
-                    else { offa = (unsigned)(r0 * ROWB + dt * 32 + p4 * 8); offb = offa + 16 * ROWB; }
-                    kr[u][0] = ab_tr_read(lds0 + offa); kr[u][1] = ab_tr_read(lds0 + offb);
-                    sr[u][0] = *reinterpret_cast<const uint2*>(dSs + (qt * 16 + fr) * AB_DS_STRIDE + ks * 32 + 4 * g);
-                    sr[u][1] = *reinterpret_cast<const uint2*>(dSs + (qt * 16 + fr) * AB_DS_STRIDE + ks * 32 + 16 + 4 * g);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (ks0 + u >= nks) continue;
-                    const u32x4 ka = (u32x4){kr[u][0][0], kr[u][0][1], kr[u][1][0], kr[u][1][1]}, sbv = (u32x4){sr[u][0].x, sr[u][0].y, sr[u][1].x, sr[u][1].y};
-                    qacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, sbv), qacc, 0, 0, 0);
-                }
-            }
-            const int q = q0 + qt * 16 + fr;           // D rows = d (4g + e), column = query fr
-            if (q < Tn) {
-                if (gridDim.y == 1) {
-                    uint2 ov;
-                    ov.x = (unsigned)f32_to_bf16_bits(qacc[0] * scale) | ((unsigned)f32_to_bf16_bits(qacc[1] * scale) << 16);
-                    ov.y = (unsigned)f32_to_bf16_bits(qacc[2] * scale) | ((unsigned)f32_to_bf16_bits(qacc[3] * scale) << 16);
-                    *reinterpret_cast<uint2*>(dqkv + ((size_t)b * Tn + q) * ld_qkv + (size_t)h * HD + dt * 16 + g * 4) = ov;
-                } else {
-                    float* ap = dq_accum + ((size_t)b * Tn + q) * D + (size_t)h * HD + dt * 16 + g * 4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) atomicAdd(ap + e, qacc[e] * scale);
-                }
-            }
-        }
-        // (the next iteration's first barrier separates these dS reads from the next step's dS writes)
+        // next slice into the other buffer: its last readers were step st-1's phases, all before this step's barrier.  (The atomics form of
+        // delta, HD = 80, needs its zeroing above ordered before these adds: one more barrier there.)
+        if (CH != 8) __syncthreads();
+        if (st + 1 < nstep) commit(buf ^ 1);
     }
+    __syncthreads();
+    dq_phase((nstep - 1) * 32, dSs0 + ((nstep - 1) & 1) * 32 * AB_DS_STRIDE);
     // ---- dK, dV of this wave's keys: lane holds 4 consecutive d of one key
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -315,7 +324,7 @@ template <int HD>
 int launch_attention_bwd2(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* dq_accum, int64_t B, int64_t T, int64_t H,
                           int64_t ld_qkv, int64_t ld_o, float scale, hipStream_t s) {
     using C = AbCfg<HD>;
-    const size_t shm = (size_t)AB_KEYS * C::ROWB + 4 * 32 * C::ROWB + 32 * AB_DS_STRIDE * 2 + 128 * 4;
+    const size_t shm = (size_t)AB_KEYS * C::ROWB + 4 * 32 * C::ROWB + 2 * 32 * AB_DS_STRIDE * 2 + 128 * 4;
     hipError_t e = hipFuncSetAttribute((const void*)attention_bwd2_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) { occ_set_error("occ_attention_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
     const int64_t nkb = occ_cdiv(T, AB_KEYS);
