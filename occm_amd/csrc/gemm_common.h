@@ -215,12 +215,62 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
     static_assert(NJ % 2 == 0, "row epilogue works on pairs of 16-row blocks");
     constexpr int RS = 272;
     const int fr = lane & 15, fq = lane >> 4;
+    const bool plain_c = a.cmap.rpl == 0 && a.cmap.rpb >= a.M, plain_r = !HASR || (a.rmap.rpl == 0 && a.rmap.rpb >= a.M);
+    const float al = a.alpha * (a.dq_a ? *a.dq_a : 1.f) * (a.dq_w ? *a.dq_w : 1.f);       // (1.0 for the bf16 path: the product below is exact)
+    if constexpr (CBF && !HASR) {
+        // bf16 results (and the bf16 side tensor): EIGHT columns per lane, a row per 8 lanes -- 16-byte stores, eight rows per instruction
+        const int rr = lane >> 3, cc = lane & 7;
+        const long long n = ncol0 + cc * 8;
+        f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        const bool whole = n + 8 <= a.N;
+        if (HASB && n < a.N) { b0 = *reinterpret_cast<const f32x4*>(a.bias + n); if (whole) b1 = *reinterpret_cast<const f32x4*>(a.bias + n + 4); }
+#pragma unroll
+        for (int ch = 0; ch < NJ / 2; ++ch) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<f32x4*>(lds_wave + (jj * 16 + fr) * RS + i * 64 + fq * 16) = acc[i][ch * 2 + jj];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rloc = k * 8 + rr;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(lds_wave + rloc * RS + cc * 32), v1 = *reinterpret_cast<const f32x4*>(lds_wave + rloc * RS + cc * 32 + 16);
+                const long long m = mrow0 + ch * 32 + rloc;
+                if (m >= a.M || n >= a.N || ch * 32 + rloc >= rows) continue;
+                const long long coff = (plain_c ? m * a.cmap.rstride : row_off(a.cmap, m)) + n;
+                v0 = v0 * al; v1 = v1 * al;
+                if (HASB) { v0 += b0; v1 += b1; }
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                auto pack = [&](uint4& o) {
+                    o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16); o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                    o.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16); o.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+                };
+                if (AUXM == 1) {
+                    uint4 o; pack(o);
+                    if (whole) *reinterpret_cast<uint4*>(a.aux + coff) = o;
+                    else { *reinterpret_cast<uint2*>(a.aux + coff) = make_uint2(o.x, o.y); }          // N % 4 == 0: a ragged last group is 4 columns
+                }
+                if (AUXM == 2) {
+                    const uint4 u = whole ? *reinterpret_cast<const uint4*>(a.aux + coff) : make_uint4(reinterpret_cast<const uint2*>(a.aux + coff)->x, reinterpret_cast<const uint2*>(a.aux + coff)->y, 0, 0);
+                    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[2 * e] *= gelu_grad(bf16_bits_to_f32((unsigned short)(w[e] & 0xffff))); v[2 * e + 1] *= gelu_grad(bf16_bits_to_f32((unsigned short)(w[e] >> 16))); }
+                }
+                if (GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                }
+                uint4 o; pack(o);
+                if (whole) *reinterpret_cast<uint4*>(a.C + coff * 2) = o;
+                else *reinterpret_cast<uint2*>(a.C + coff * 2) = make_uint2(o.x, o.y);
+            }
+        }
+        return;
+    }
     const int rr = lane >> 4, cc = lane & 15;                  // read-back: row rr (+4k) of the chunk, columns 4*cc .. 4*cc+3
     const long long n = ncol0 + cc * 4;
-    const bool plain_c = a.cmap.rpl == 0 && a.cmap.rpb >= a.M, plain_r = !HASR || (a.rmap.rpl == 0 && a.rmap.rpb >= a.M);
     f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (HASB && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
-    const float al = a.alpha * (a.dq_a ? *a.dq_a : 1.f) * (a.dq_w ? *a.dq_w : 1.f);       // (1.0 for the bf16 path: the product below is exact)
 #pragma unroll
     for (int ch = 0; ch < NJ / 2; ++ch) {
 #pragma unroll

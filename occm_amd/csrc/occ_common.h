@@ -89,10 +89,18 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x * exp(-x^2/2) / sqrt(2 pi)
+// (one exponential serves both terms: erf's exp(-(x/sqrt2)^2) is the density's exp(-x^2/2))
 __device__ __forceinline__ float gelu_grad(float x) {
-    const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.5f * x * x * 1.44269504088896340736f);
-    return fmaf(x, pdf, cdf);
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+    const float cdf = 0.5f * (1.0f + copysignf(fmaf(-p, e, 1.0f), x));
+    return fmaf(x, 0.39894228040143267794f * e, cdf);
 }
 __device__ __forceinline__ float selu_f(float x) {
     const float a = 1.6732632423543772848170429916717f, s = 1.0507009873554804934193349852946f;
