@@ -180,7 +180,8 @@ def usable_cores():
 
 
 def cpu_baseline(finetune, rawboost, budget_s=25.0):
-    """The torch-CPU oracle (kind "port": the reference's fairseq front-end cannot run) on a bounded sample of the same step at bs=2:
+    """The torch-CPU oracle (kind "port": the reference's fairseq front-end cannot run) on a bounded sample of the same step at bs=8
+    (SURVEY.md section 8d):
     (numpy RawBoost ->) XLS-R-300M (forward only when frozen, forward + backward when fine-tuned) -> AASIST fwd/bwd -> Adam over
     every trained parameter; as many steps as fit the budget (>= 1)."""
     import numpy as np
@@ -196,7 +197,7 @@ def cpu_baseline(finetune, rawboost, budget_s=25.0):
     if finetune:
         train += [v.requires_grad_(True) for v in px.values()]
     opt = torch.optim.Adam(train, lr=1e-5)
-    B = 2
+    B = 8
     wav, labels = synth_batch(B, 0, "cpu")
     rb_args = None
     if rawboost:
