@@ -425,3 +425,24 @@ def test_finetune_loop_three_steps_track_the_oracle_loop():
         worst = min(worst, cos)
         assert cos >= 0.6, (name, cos)
     print("three-step loop: losses", got, "vs oracle", ref_losses, "worst update cosine %.3f" % worst)
+
+
+def test_transpose_bf16_batch_one_launch_many_jobs():
+    """occ_transpose_bf16_batch: bf16 and f32 sources, whole and ragged 64x64 tiles, strided source / destination rows, several jobs
+    in one launch -- every destination equals the single-job transpose, pad columns untouched."""
+    from occm_amd import ops
+    g = torch.Generator().manual_seed(0)
+    tb = ops.TransposeBatch()
+    cases = []
+    for rows, cols, ld_src, ld_dst, dt in ((1024, 1024, 1024, 1024, torch.bfloat16), (4096, 1024, 1024, 4096, torch.bfloat16), (512, 512, 1536, 1024, torch.bfloat16),
+                                          (100, 36, 40, 104, torch.bfloat16), (130, 70, 70, 136, torch.float32), (64, 64, 64, 64, torch.float32)):
+        src = torch.randn(rows, ld_src, generator=g).to(dt).cuda()
+        dst = torch.full((cols, ld_dst), 7.0, device="cuda", dtype=torch.bfloat16)
+        tb.add(src, dst, rows, cols, ld_src=ld_src, ld_dst=ld_dst)
+        cases.append((src, dst, rows, cols))
+    tb.run()
+    tb.run()                                                     # the job table is reused
+    for src, dst, rows, cols in cases:
+        ref = src[:, :cols].float().t().bfloat16()
+        assert torch.equal(dst[:, :rows], ref)
+        assert bool((dst[:, rows:] == 7.0).all())
