@@ -135,6 +135,11 @@ int occ_gemm(const occ_gemm_desc* d, void* stream);
  * dst[i] = fp8(src[i] * *scale) saturating at the format's largest finite value (src f32 or bf16, fmt OCC_FP8_E4M3 / OCC_FP8_E5M2);
  * scale: device scalar or NULL (= 1); amax: device scalar or NULL, raised to max |src[i]| (atomic max) for the NEXT step's scale. */
 int occ_fp8_quantize(const void* src, int src_dtype, void* dst, int fmt, int64_t n, const float* scale, float* amax, void* stream);
+/* Many bf16 tensors in ONE launch: job i quantises src[0..n) (n % 8 == 0, 16-byte aligned) into dst with *scale (NULL = 1) and raises
+ * *amax (NULL = not tracked); dst == NULL measures |max| only.  The job array lives in DEVICE memory, sorted by first_chunk = number of
+ * 8192-element chunks of the jobs before it; total_chunks = their sum.                                                         */
+typedef struct occ_fp8_job { const void* src; void* dst; int64_t n; const float* scale; float* amax; int64_t first_chunk; } occ_fp8_job;
+int occ_fp8_quantize_batch(const occ_fp8_job* jobs_dev, int64_t n_jobs, int64_t total_chunks, int fmt, void* stream);
 /* amax[i] = max |src| only (current scaling: the first step of a site, weights).                                            */
 int occ_fp8_amax(const void* src, int src_dtype, int64_t n, float* amax, void* stream);
 /* For n sites: scale[i] = fmax / (amax[i] * margin) (1 when amax[i] == 0), inv_scale[i] = 1 / scale[i], amax[i] = 0.

@@ -531,18 +531,19 @@ class XlsrFineTuner(XlsrFrontend):
     def _fp8_weights(self):
         """Weights: |max| of the bf16 mirror now -> scale -> e4m3 copies of W and W^T (same scale)."""
         f8 = self.f8
-        for name in f8["wq"]:
-            i, wn = int(name[1:name.index(".")]), name[name.index(".") + 1:]
-            k = i * 8 + self._E4[wn]
-            ops.fp8_amax(self.w[name], f8["amax4"][k:k + 1])
+        if "w_amax" not in f8:                                   # two launches for all weights: |max| of every W, then W and W^T quantised
+            f8["w_amax"], f8["w_quant"] = ops.Fp8Batch(f8["e4"]), ops.Fp8Batch(f8["e4"])
+            for name in f8["wq"]:
+                i, wn = int(name[1:name.index(".")]), name[name.index(".") + 1:]
+                k = i * 8 + self._E4[wn]
+                f8["w_amax"].add(self.w[name], amax=f8["amax4"][k:k + 1])
+                f8["w_quant"].add(self.w[name], f8["wq"][name], scale=f8["scale4"][k:k + 1])
+                f8["w_quant"].add(self.wT[name], f8["wtq"][name], scale=f8["scale4"][k:k + 1])
+        f8["w_amax"].run()
         # one pass over every e4m3 / e5m2 site: the activation and gradient sites pick up this step's |max| for the next step
         ops.fp8_update_scales(f8["amax4"], f8["scale4"], f8["inv4"], f8["e4"], f8["margin"])
         ops.fp8_update_scales(f8["amax5"], f8["scale5"], f8["inv5"], f8["e5"], f8["margin"])
-        for name in f8["wq"]:
-            i, wn = int(name[1:name.index(".")]), name[name.index(".") + 1:]
-            k = i * 8 + self._E4[wn]
-            ops.fp8_quantize(self.w[name], f8["wq"][name], f8["e4"], scale=f8["scale4"][k:k + 1])
-            ops.fp8_quantize(self.wT[name], f8["wtq"][name], f8["e4"], scale=f8["scale4"][k:k + 1])
+        f8["w_quant"].run()
 
     def _fp8_q(self, x, kind, k):
         """x (bf16 / f32) -> fp8 scratch; kind 4 = e4m3 activation site, 5 = e5m2 gradient site; returns (buffer, inverse-scale scalar)."""

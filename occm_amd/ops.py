@@ -152,6 +152,31 @@ def transpose_bf16_rows(src, src_map, dst, rows, cols, ld_dst, colsum=None, src_
     return dst
 
 
+class Fp8Batch:
+    """A fixed set of bf16 tensors quantised (or only measured: dst None) in ONE launch (occ_fp8_quantize_batch).  scale / amax are
+    one-element device tensors (views into the per-site arrays) or None; the job table is uploaded on the first run()."""
+
+    def __init__(self, fmt):
+        self.fmt, self.jobs, self.chunks, self._dev, self._keep = int(fmt), [], 0, None, []
+
+    def add(self, src, dst=None, scale=None, amax=None):
+        n = src.numel()
+        assert src.dtype == torch.bfloat16 and n % 8 == 0 and src.is_contiguous()
+        self.jobs.append((src.data_ptr(), 0 if dst is None else dst.data_ptr(), n, 0 if scale is None else scale.data_ptr(),
+                          0 if amax is None else amax.data_ptr(), self.chunks))
+        self.chunks += (n + 8191) // 8192
+        self._keep.append((src, dst, scale, amax))
+        self._dev = None
+
+    def run(self):
+        if not self.jobs:
+            return
+        if self._dev is None:
+            import numpy as np
+            self._dev = torch.from_numpy(np.asarray(self.jobs, dtype=np.int64)).cuda()
+        check(lib().occ_fp8_quantize_batch(ptr(self._dev), len(self.jobs), self.chunks, self.fmt, stream_ptr()), "occ_fp8_quantize_batch")
+
+
 class TransposeBatch:
     """A fixed set of transposes dst[c, r] = bf16(src[r, c]) run as ONE launch (occ_transpose_bf16_batch).  add() takes tensors or int device
     addresses; the job table is uploaded on the first run() and the operands must not move afterwards."""
