@@ -60,8 +60,12 @@ def canonical_len(T):
     return (T - 1) * 320 + 400
 
 
-def embed_dataset(model, dataloader, device, batch_size=1):
+def embed_dataset(model, dataloader, device, batch_size=1, rank=0, world=1):
     """(emb [N,160], logits [N,2]) of every utterance, in dataset order.
+
+    world > 1 (one process per GPU, torch.distributed initialised): rank r embeds the utterances whose position p has p % world == r
+    -- the loader must then be built over ``shard_dataset(dataset, rank, world)`` -- and a sum all-reduce of the zero-initialised
+    result tensors gives every rank the whole set ("shard the file list, all-gather the embeddings").
 
     batch_size 1 is the reference's loop (oc_classifier.py:182-186, 243-265: one utterance per forward).  batch_size > 1 buckets by
     frame count: utterances with the same number of frames, cropped to that count's canonical length, form one batch, so no padding
@@ -69,12 +73,14 @@ def embed_dataset(model, dataloader, device, batch_size=1):
     kernels picked for a different row count (summation order).  Buckets fill as the loader delivers utterances; at most
     (#distinct frame counts in flight) x batch_size waveforms are held."""
     model.eval()
-    n = len(dataloader.dataset)
-    embs, logits = torch.empty(n, 160, device=device), torch.empty(n, 2, device=device)
+    ds = dataloader.dataset
+    n_local = len(ds)
+    n = getattr(ds, "full_len", n_local)                     # shard_dataset records the length of the whole set
+    embs, logits = torch.zeros(n, 160, device=device), torch.zeros(n, 2, device=device)
     pending = {}
 
     def flush(items):
-        idxs = torch.tensor([i for i, _ in items], device=device)
+        idxs = torch.tensor([i * world + rank if world > 1 else i for i, _ in items], device=device)
         emb, out = model(torch.stack([w for _, w in items]).to(device))
         embs[idxs] = emb.float(); logits[idxs] = out.float()
 
@@ -95,44 +101,68 @@ def embed_dataset(model, dataloader, device, batch_size=1):
                 pos += 1
         for T in sorted(pending):
             flush(pending[T])
-    if pos != n:
-        raise RuntimeError("loader delivered %d of %d utterances" % (pos, n))
+    if pos != n_local:
+        raise RuntimeError("loader delivered %d of %d utterances" % (pos, n_local))
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(embs); dist.all_reduce(logits)
     return embs, logits
 
 
-def create_reference_embedding2(model, dataloader, device, cache=True, batch_size=1):
+class _Shard(torch.utils.data.Dataset):
+    def __init__(self, base, rank, world):
+        self.base, self.rank, self.world, self.full_len = base, rank, world, len(base)
+
+    def __len__(self):
+        return (self.full_len - self.rank + self.world - 1) // self.world
+
+    def __getitem__(self, i):
+        return self.base[i * self.world + self.rank]
+
+
+def shard_dataset(dataset, rank, world):
+    """Utterances rank, rank + world, ... of the set (the whole set on one rank)."""
+    return dataset if world <= 1 else _Shard(dataset, rank, world)
+
+
+def create_reference_embedding2(model, dataloader, device, cache=True, batch_size=1, rank=0, world=1):
     """oc_classifier.py:159-202: mean embedding of the bona-fide set, threshold = largest distance to it."""
     if cache and os.path.exists("reference_embedding.pt") and os.path.exists("threshold.pt"):
         print("Loading reference embedding and threshold...")
         return torch.load("reference_embedding.pt"), torch.load("threshold.pt")
     print("Creating a reference embedding...")
-    embs, _ = embed_dataset(model, dataloader, device, batch_size)      # [N,160]
+    embs, _ = embed_dataset(model, dataloader, device, batch_size, rank, world)      # [N,160]
     reference_embedding = embs.mean(dim=0, keepdim=True)            # [1,160] like torch.mean(torch.stack(..), 0)
     dist = ops.pairwise_dist(reference_embedding.reshape(-1).contiguous(), embs.contiguous())
-    with open("distances.txt", "a") as f:
-        for d in dist.tolist():
-            f.write(f"{d}\n")
+    if rank == 0:
+        with open("distances.txt", "a") as f:
+            for d in dist.tolist():
+                f.write(f"{d}\n")
     threshold = dist.max()
-    if cache:
+    if cache and rank == 0:
         torch.save(reference_embedding, "reference_embedding.pt")
         torch.save(threshold, "threshold.pt")
     return reference_embedding, threshold
 
 
-def score_eval_set_1c2(model, dataloader, device, reference_embedding, threshold, path="scores.txt", batch_size=1):
+def score_eval_set_1c2(model, dataloader, device, reference_embedding, threshold, path="scores.txt", batch_size=1, rank=0, world=1):
     """One-class scoring (oc_classifier.py:243-265): distance to the reference embedding, 1 when above the threshold."""
     thr = float(threshold)
     print("Scoring the evaluation set...")
-    embs, _ = embed_dataset(model, dataloader, device, batch_size)
+    embs, _ = embed_dataset(model, dataloader, device, batch_size, rank, world)
     dist = ops.pairwise_dist(reference_embedding.reshape(-1).contiguous(), embs.contiguous()).tolist()
+    if rank != 0:
+        return
     with open(path, "w") as f:
         for d in dist:
             f.write(f"{d}, 1 \n" if d > thr else f"{d}, 0 \n")
 
 
-def score_eval_set_2c2(model, dataloader, device, path="scores.txt", batch_size=1):
+def score_eval_set_2c2(model, dataloader, device, path="scores.txt", batch_size=1, rank=0, world=1):
     """Two-class scoring (oc_classifier.py:292-312): the bona-fide logit."""
-    _, logits = embed_dataset(model, dataloader, device, batch_size)
+    _, logits = embed_dataset(model, dataloader, device, batch_size, rank, world)
+    if rank != 0:
+        return
     with open(path, "w") as f:
         for v in logits[:, 0].tolist():
             f.write(f"{v}\n")
@@ -152,6 +182,10 @@ def main(argv=None):
     parser.add_argument("--num_workers", type=int, default=0)
     args = parser.parse_args(argv)
     from .models.sslassist import AModel
+    from . import parallel
+    rank, world, local = parallel.init_from_env()              # torchrun --nproc-per-node N: the file lists are sharded over the ranks
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     device = torch.device("cuda")
     # The reference builds AModel (which loads the fairseq file from a hard-coded path) and then overwrites every tensor with the trained
     # checkpoint (oc_classifier.py:335-340, strict).  That checkpoint already holds all ``ssl_model.model.*`` tensors, so here it is the one
@@ -161,13 +195,15 @@ def main(argv=None):
     aasist = AModel(None, device, ssl_state_dict=ssl)
     aasist.load_state_dict(sd, strict=True)
     print("Pretrained weights loaded")
-    train_loader = DataLoader(ASVDataset(args.protocol_file, args.dataset_dir), batch_size=1, shuffle=False, num_workers=args.num_workers)
-    reference_embedding, threshold = create_reference_embedding2(aasist, train_loader, device, batch_size=args.batch_size)
-    eval_loader = DataLoader(ASVDataset(args.eval_protocol_file, args.eval_dataset_dir, eval=True), batch_size=1, shuffle=False, num_workers=args.num_workers)
+    kw = dict(batch_size=args.batch_size, rank=rank, world=world)
+    train_loader = DataLoader(shard_dataset(ASVDataset(args.protocol_file, args.dataset_dir), rank, world), batch_size=1, shuffle=False, num_workers=args.num_workers)
+    reference_embedding, threshold = create_reference_embedding2(aasist, train_loader, device, **kw)
+    eval_loader = DataLoader(shard_dataset(ASVDataset(args.eval_protocol_file, args.eval_dataset_dir, eval=True), rank, world), batch_size=1, shuffle=False,
+                             num_workers=args.num_workers)
     if args.two_class:
-        score_eval_set_2c2(aasist, eval_loader, device, batch_size=args.batch_size)
+        score_eval_set_2c2(aasist, eval_loader, device, **kw)
     else:
-        score_eval_set_1c2(aasist, eval_loader, device, reference_embedding, threshold, batch_size=args.batch_size)
+        score_eval_set_1c2(aasist, eval_loader, device, reference_embedding, threshold, **kw)
     print(f"threshold = {threshold}")
 
 

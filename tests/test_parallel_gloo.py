@@ -67,3 +67,65 @@ def test_shard_groups_covers_everything_once():
         for w in (1, 2, 3, 8):
             cuts = [shard_groups(n, r, w) for r in range(w)]
             assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+
+
+class _FakeScorer:
+    """Stands in for AModel on the CPU: (emb [B,160], logits [B,2]) as a deterministic function of each utterance."""
+
+    def eval(self):
+        return self
+
+    def __call__(self, x):
+        m, s = x.mean(dim=1, keepdim=True), x.std(dim=1, keepdim=True)
+        emb = m * torch.arange(160.0)[None] + s
+        return emb, torch.cat([m, s], dim=1)
+
+
+class _Utts(torch.utils.data.Dataset):
+    LENS = [9000, 8720, 9039, 12000, 8800, 12100, 8900, 15000, 8999, 12239, 8721]
+
+    def __len__(self):
+        return len(self.LENS)
+
+    def __getitem__(self, i):
+        return torch.randn(self.LENS[i], generator=torch.Generator().manual_seed(i)), torch.tensor([0])
+
+
+def _score_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from occm_amd import parallel
+    from occm_amd.oc_classifier import embed_dataset, shard_dataset
+    parallel.init_from_env(backend="gloo")
+    res = []
+    for bs in (1, 3):
+        dl = torch.utils.data.DataLoader(shard_dataset(_Utts(), rank, world), batch_size=1, shuffle=False)
+        e, l = embed_dataset(_FakeScorer(), dl, "cpu", batch_size=bs, rank=rank, world=world)
+        res.append((e.numpy().copy(), l.numpy().copy()))         # plain arrays: tensors in a Queue live in shared memory of a process that exits
+    torch.distributed.destroy_process_group()
+    out.put((rank, res))
+
+
+def test_sharded_scoring_world2_equals_single_process():
+    """oc_classifier.embed_dataset with the file list sharded over two ranks (gloo): every rank ends up with the embeddings of the whole
+    set, in dataset order, equal to the single-process result -- one at a time and bucketed by frame count."""
+    from occm_amd.oc_classifier import canonical_len, embed_dataset, n_frames
+    single = {}
+    for bs in (1, 3):
+        dl = torch.utils.data.DataLoader(_Utts(), batch_size=1, shuffle=False)
+        single[bs] = embed_dataset(_FakeScorer(), dl, "cpu", batch_size=bs)
+    # bucketing crops to the canonical length, so the fake scorer (which looks at every sample) differs between bs 1 and 3 by design
+    x0 = _Utts()[0][0]
+    assert single[3][0].shape == (11, 160) and torch.allclose(single[3][0][0], _FakeScorer()(x0[None, :canonical_len(n_frames(x0.numel()))])[0][0])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_score_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        for k, bs in enumerate((1, 3)):
+            assert torch.allclose(torch.from_numpy(got[rank][k][0]), single[bs][0], atol=1e-6) and torch.allclose(torch.from_numpy(got[rank][k][1]), single[bs][1], atol=1e-6)
