@@ -173,10 +173,20 @@ class OcTrainer:
 
     def _step_finetune(self, wav, labels, next_wav=None, next_step=0):
         be, fe = self.be, self.fe
+        # the front-end's gradient buffer (1.26 GB) is cleared on the side stream while the forward pass runs: nothing reads it before
+        # the backward pass, and the previous step's optimizer (its last reader) is already enqueued on the main stream
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=wav.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            fe.zero_grad()
+            cleared = torch.cuda.Event()
+            cleared.record(self._side)
         feats = fe.forward_train(wav)
         if next_wav is not None:
             self._prefetch_augment(next_wav, next_step)
-        fe.zero_grad()
+        main.wait_event(cleared)
         lc, ld, dfeats = self._backend_section(feats, labels, True)
         # each transformer layer's 50 MB of gradients go to RCCL as soon as that layer's backward is enqueued (last layer first);
         # the conv stack, the back-end and anything left over follow at the end
