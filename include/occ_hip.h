@@ -82,6 +82,15 @@ int occ_compactness_loss(const float* emb, float* loss, float* demb, int64_t n_g
  * dlogits (may be NULL) receives d(loss*scale)/dlogits.                                          */
 int occ_ce_loss(const float* logits, const int64_t* labels, float* loss, float* dlogits, int64_t B,
                 int64_t C, float scale, void* stream);
+/* Signed sum of pair distances with F.pairwise_distance's eps: loss[0] = act(bias + sum_k weights[k] *
+ * ||emb[pair_i[k]] - emb[pair_j[k]] + 1e-6||_2), act = relu when `relu` != 0.  Replaces triplet_loss
+ * (custom_loss.py:32-57: pairs (0,1) weight +1, (0,2) weight -1, bias = margin, relu) and
+ * euclidean_distance_loss (custom_loss.py:59-74: pairs (0,1),(0,2),(0,3),(2,1),(2,3), weights 1/5).
+ * pair_i / pair_j i32 [n_pairs] and weights f32 [n_pairs] are device arrays, n_pairs <= 16; the row indices must be
+ * < R (caller-checked).  demb f32 [R,E] (may be NULL) receives d(loss*scale)/d(emb).                    */
+int occ_pair_dist_loss(const float* emb, const int32_t* pair_i, const int32_t* pair_j, const float* weights,
+                       int64_t n_pairs, float bias, int relu, float* loss, float* demb, int64_t R, int64_t E,
+                       float scale, void* stream);
 /* F.pairwise_distance(ref, emb) of oc_classifier.py:193, 261: dist[i] = ||ref - emb[i] + 1e-6||_2.  */
 int occ_pairwise_dist(const float* ref, const float* emb, float* dist, int64_t N, int64_t E, void* stream);
 
@@ -142,7 +151,8 @@ typedef struct occ_fp8_job { const void* src; void* dst; int64_t n; const float*
 int occ_fp8_quantize_batch(const occ_fp8_job* jobs_dev, int64_t n_jobs, int64_t total_chunks, int fmt, void* stream);
 /* amax[i] = max |src| only (current scaling: the first step of a site, weights).                                            */
 int occ_fp8_amax(const void* src, int src_dtype, int64_t n, float* amax, void* stream);
-/* For n sites: scale[i] = fmax / (amax[i] * margin) (1 when amax[i] == 0), inv_scale[i] = 1 / scale[i], amax[i] = 0.
+/* For n sites: scale[i] = fmax / (amax[i] * margin), inv_scale[i] = 1 / scale[i] (both left unchanged when amax[i] == 0:
+ * nothing was measured since the last update), then amax[i] = 0.
  * fmax: 448 (e4m3) or 57344 (e5m2).                                                                                          */
 int occ_fp8_update_scales(float* amax, float* scale, float* inv_scale, int64_t n, float fmax, float margin, void* stream);
 

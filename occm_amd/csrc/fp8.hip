@@ -109,8 +109,11 @@ __global__ void fp8_update_scales_kernel(float* __restrict__ amax, float* __rest
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float a = amax[i];
-    const float sc = a > 0.f ? fmax / (a * margin) : 1.f;
-    scale[i] = sc; inv[i] = 1.f / sc; amax[i] = 0.f;
+    if (a > 0.f) {                       // a site with no measurement since the last update (layer skipped by layerdrop, a second refresh
+        const float sc = fmax / (a * margin);   // without a step in between) keeps its delayed scale instead of falling back to 1
+        scale[i] = sc; inv[i] = 1.f / sc;
+    }
+    amax[i] = 0.f;
 }
 
 template <bool QUANT>

@@ -103,6 +103,43 @@ __global__ void pairwise_dist_kernel(const float* __restrict__ ref, const float*
     if (lane == 0) dist[row] = sqrtf(s);
 }
 
+// Signed sum of pair distances: loss = act(bias + sum_k w[k] * ||e[pi[k]] - e[pj[k]] + eps||), act = relu or identity
+// (triplet_loss custom_loss.py:32-57: pairs (0,1,+1), (0,2,-1), bias = margin, relu; euclidean_distance_loss :59-74: five pairs of
+// weight 1/5).  One workgroup, pairs walked in order (reproducible); demb = d(loss * scale)/d(emb), zero where the relu is shut.
+constexpr int PAIR_MAX = 16;
+__global__ __launch_bounds__(LOSS_THREADS) void pair_dist_loss_kernel(const float* __restrict__ emb, const int32_t* __restrict__ pi,
+                                                                       const int32_t* __restrict__ pj, const float* __restrict__ w, int n_pairs,
+                                                                       float bias, int relu, float* __restrict__ loss, float* __restrict__ demb,
+                                                                       int R, int E, float scale) {
+    __shared__ float red[4];
+    __shared__ float coef[PAIR_MAX];
+    float total = bias;
+    for (int k = 0; k < n_pairs; ++k) {
+        const float* a = emb + (size_t)pi[k] * E;
+        const float* b = emb + (size_t)pj[k] * E;
+        float s = 0.f;
+        for (int c = threadIdx.x; c < E; c += LOSS_THREADS) { const float d = a[c] - b[c] + PAIR_EPS; s += d * d; }
+        const float dist = sqrtf(block_sum_256(s, red));
+        total += w[k] * dist;
+        if (threadIdx.x == 0) coef[k] = dist > 0.f ? w[k] / dist : 0.f;
+    }
+    const bool open_ = !relu || total > 0.f;
+    if (threadIdx.x == 0) loss[0] = open_ ? total : 0.f;
+    if (!demb) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * E; i += LOSS_THREADS) demb[i] = 0.f;
+    __syncthreads();
+    if (!open_) return;
+    for (int k = 0; k < n_pairs; ++k) {                  // pairs in order, one column per thread: no two threads touch one element
+        const int ia = pi[k], ib = pj[k];
+        for (int c = threadIdx.x; c < E; c += LOSS_THREADS) {
+            const float g = scale * coef[k] * (emb[(size_t)ia * E + c] - emb[(size_t)ib * E + c] + PAIR_EPS);
+            demb[(size_t)ia * E + c] += g;
+            demb[(size_t)ib * E + c] -= g;
+        }
+    }
+}
+
 // torch.optim.Adam keeps one step counter per parameter and skips parameters whose grad is None.
 __global__ void adam_bump_steps_kernel(void* const* __restrict__ grads, int32_t* __restrict__ steps, int n) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,6 +217,16 @@ int occ_pairwise_dist(const float* ref, const float* emb, float* dist, int64_t N
     OCC_CHECK_ARG(ref && emb && dist && N >= 1 && E >= 1, "occ_pairwise_dist: bad argument");
     hipLaunchKernelGGL(pairwise_dist_kernel, dim3((unsigned)occ_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, ref, emb, dist, (int)N, (int)E);
     OCC_LAUNCH_CHECK("occ_pairwise_dist");
+    return OCC_OK;
+}
+
+int occ_pair_dist_loss(const float* emb, const int32_t* pair_i, const int32_t* pair_j, const float* weights, int64_t n_pairs, float bias, int relu,
+                       float* loss, float* demb, int64_t R, int64_t E, float scale, void* stream) {
+    OCC_CHECK_ARG(emb && pair_i && pair_j && weights && loss, "occ_pair_dist_loss: null pointer");
+    OCC_CHECK_ARG(n_pairs >= 1 && n_pairs <= PAIR_MAX && R >= 1 && E >= 1, "occ_pair_dist_loss: needs 1..%d pairs (got %ld)", PAIR_MAX, (long)n_pairs);
+    hipLaunchKernelGGL(pair_dist_loss_kernel, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, emb, pair_i, pair_j, weights, (int)n_pairs, bias, relu,
+                       loss, demb, (int)R, (int)E, scale);
+    OCC_LAUNCH_CHECK("occ_pair_dist_loss");
     return OCC_OK;
 }
 

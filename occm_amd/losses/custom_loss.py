@@ -45,21 +45,26 @@ def descriptiveness_loss(batch_embeddings, labels):
     return _Descriptiveness.apply(batch_embeddings, labels)
 
 
-def _dist(a, b):
-    return ops.pairwise_dist(a.contiguous().float().reshape(-1), b.contiguous().float().reshape(1, -1))
+class _PairDist(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, pairs, weights, bias, relu):
+        loss, demb = ops.pair_dist_loss(emb.contiguous().float(), pairs, weights, bias=bias, relu=relu, want_grad=True)
+        ctx.save_for_backward(demb)
+        return loss                                              # shape [1], as F.pairwise_distance of two [1,E] rows gives
+
+    @staticmethod
+    def backward(ctx, g):
+        (demb,) = ctx.saved_tensors
+        return demb * g, None, None, None, None
 
 
 def triplet_loss(batch_embeddings, margin=9.0):
-    """custom_loss.py:32-57 (forward only: the reference never trains with it, oc_training.py:379)."""
-    e = batch_embeddings.detach()
-    return torch.relu(_dist(e[0], e[1]) - _dist(e[0], e[2]) + margin)
+    """custom_loss.py:32-57: relu(||bona1 - bona2|| - ||bona1 - spoof1|| + margin) on rows [0, 1, 2]; value and gradient from
+    occ_pair_dist_loss."""
+    return _PairDist.apply(batch_embeddings, ((0, 1), (0, 2)), (1.0, -1.0), float(margin), True)
 
 
 def euclidean_distance_loss(batch_embeddings):
-    """custom_loss.py:59-74 (forward only)."""
-    e = batch_embeddings.detach()
-    pairs = [(0, 1), (0, 2), (0, 3), (2, 1), (2, 3)]
-    loss = 0.0
-    for i, j in pairs:
-        loss = loss + _dist(e[i], e[j])
-    return loss / len(pairs)
+    """custom_loss.py:59-74: mean distance over the pairs (0,1), (0,2), (0,3), (2,1), (2,3)."""
+    pairs = ((0, 1), (0, 2), (0, 3), (2, 1), (2, 3))
+    return _PairDist.apply(batch_embeddings, pairs, (1.0 / len(pairs),) * len(pairs), 0.0, False)

@@ -400,6 +400,13 @@ class XlsrFineTuner(XlsrFrontend):
         self.drop_seed, self.drop_step = 0, 0
         self.inject_masks, self.inject_keep = None, None
         self.masks, self.keep = {}, None
+        self.seed_layerdrop(0)
+
+    def seed_layerdrop(self, seed):
+        """Layerdrop decisions come from a per-trainer generator (fairseq draws np.random.random() per layer from the global stream):
+        reproducible from (seed, rank), independent across data-parallel ranks."""
+        import numpy as np
+        self._ld_rng = np.random.RandomState((int(seed) * 2654435761 + 12345) % (2 ** 32))
 
     def _extra_shapes(self):
         return []
@@ -619,8 +626,7 @@ class XlsrFineTuner(XlsrFrontend):
         if self.inject_keep is not None:
             self.keep = [bool(k) for k in self.inject_keep]
         elif p_ld > 0:                                           # fairseq: np.random.random() > layerdrop keeps the layer
-            import numpy as np
-            self.keep = [bool(np.random.random() > p_ld) for _ in range(cfg.layers)]
+            self.keep = [bool(self._ld_rng.random_sample() > p_ld) for _ in range(cfg.layers)]
         else:
             self.keep = [True] * cfg.layers
         if (p_res > 0 or p_act > 0) and "y" not in tr:

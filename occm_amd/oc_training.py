@@ -106,9 +106,12 @@ def main(argv=None):
     parser.add_argument("--w_descr", type=float, default=1.0)
     parser.add_argument("--vocoded_dir", type=str, default="/datab/Dataset/ASVspoof/LA/ASVspoof2019_LA_vocoded")
     parser.add_argument("--rawboost_algo", type=int, default=0)
-    parser.add_argument("--ssl_checkpoint", type=str, default="/datad/pretrained/fairseq/xlsr2_300m.pt",
+    parser.add_argument("--ssl_checkpoint", type=str, default="/datac/longnv/SSL_Anti-spoofing/pretrained/xlsr2_300m.pt",
                         help="fairseq XLS-R checkpoint ({'model': ..., 'cfg': ...} or a bare state dict); default = the path the reference hard-codes "
                         "(sslassist.py:24).  A missing file is an error, as in the reference")
+    parser.add_argument("--ssl_dtype", choices=["bf16", "f32"], default="bf16",
+                        help="arithmetic of a FROZEN XLS-R front-end and of the back-end GEMMs: bf16 MFMA with f32 accumulate (default, the throughput path) "
+                             "or f32 = exact-f32 MFMA (the 1e-3 parity path, ~8x slower).  --finetuned always trains with bf16 operands over f32 master weights")
     parser.add_argument("--synthetic_ssl", action="store_true", help="tests only: deterministic random XLS-R weights instead of a checkpoint")
     for _k in ("dropout", "attention_dropout", "activation_dropout", "encoder_layerdrop", "dropout_input"):
         parser.add_argument("--ssl_" + _k, type=float, default=None, help="fairseq train-mode %s of XLS-R when --finetuned (default: the checkpoint's cfg)" % _k)
@@ -124,6 +127,9 @@ def main(argv=None):
     if args.num_workers > 0 and args.rawboost_algo and not args.rawboost_on_gpu:
         raise ValueError("dataset-side RawBoost runs on the GPU of the main process: use --num_workers 0 or --rawboost_on_gpu")
     ssl_kw = {"synthetic_ssl": True} if args.synthetic_ssl else {"ssl_cp_path": args.ssl_checkpoint}
+    if args.finetuned and args.ssl_dtype != "bf16":
+        raise ValueError("--finetuned trains XLS-R with bf16 MFMA operands over f32 master weights; --ssl_dtype f32 applies to a frozen front-end only")
+    ssl_kw["ssl_dtype"] = torch.float32 if args.ssl_dtype == "f32" else torch.bfloat16
     if not args.synthetic_ssl and not os.path.exists(args.ssl_checkpoint):
         raise FileNotFoundError("XLS-R checkpoint %s not found (--ssl_checkpoint); the reference loads it unconditionally (sslassist.py:24-26)" % args.ssl_checkpoint)
     print("*************************************************")

@@ -344,6 +344,22 @@ def ce_loss(logits, labels, scale=1.0, want_grad=False):
     return loss, dl
 
 
+def pair_dist_loss(emb, pairs, weights, bias=0.0, relu=False, scale=1.0, want_grad=False):
+    """loss [1] = act(bias + sum_k weights[k] * ||emb[i_k] - emb[j_k] + 1e-6||); pairs = [(i, j), ...] (custom_loss.py:32-74)."""
+    _dev(emb)
+    R, E = emb.shape
+    if any(not (0 <= i < R and 0 <= j < R) for i, j in pairs):
+        raise _lib.OccError("pair_dist_loss: a pair names a row outside the %d embeddings" % R)
+    pi = torch.tensor([i for i, _ in pairs], dtype=torch.int32, device=emb.device)
+    pj = torch.tensor([j for _, j in pairs], dtype=torch.int32, device=emb.device)
+    w = torch.tensor(list(weights), dtype=torch.float32, device=emb.device)
+    loss = torch.empty(1, device=emb.device, dtype=torch.float32)
+    demb = torch.empty_like(emb) if want_grad else None
+    check(lib().occ_pair_dist_loss(ptr(emb), ptr(pi), ptr(pj), ptr(w), len(pairs), float(bias), int(bool(relu)), ptr(loss), ptr(demb), R, E, float(scale),
+                                   stream_ptr()), "occ_pair_dist_loss")
+    return loss, demb
+
+
 def pairwise_dist(ref, emb):
     _dev(emb)
     N, E = emb.shape

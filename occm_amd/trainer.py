@@ -25,6 +25,13 @@ class OcTrainer:
         self.dropout_masks = dropout_masks      # None: draw masks on the device (normal training); {}: no dropout; dict: injected keep-masks
         self.be = model.backend
         self.fe = model.ssl_model.model
+        # ... and its own dropout / layerdrop streams: DataParallel replicas draw independent masks (each replica runs its own forward),
+        # so two ranks must not share keep-masks.  Rank 0 with seed 0 keeps the streams of a single-GPU run.
+        if hasattr(self.be, "rng_seed"):
+            self.be.rng_seed = int(self.be.rng_seed) + self.seed
+        if hasattr(self.fe, "drop_seed"):
+            self.fe.drop_seed = int(self.fe.drop_seed) + self.seed
+            self.fe.seed_layerdrop(self.seed)
         self.train_frontend = train_frontend
         if train_frontend and not hasattr(self.fe, "forward_train"):
             raise ValueError("train_frontend=True needs a model built with finetune_ssl=True")
@@ -132,7 +139,8 @@ class OcTrainer:
             rec["feats"].copy_(feats); rec["labels"].copy_(labels)
             rec["graph"].replay()
             self._last_key = key
-            return rec["out"]
+            lc, ld, dfe = rec["out"]
+            return lc.clone(), ld.clone(), dfe               # (the graph rewrites its own loss scalars on the next replay: hand out copies)
         out = self._backend_eager(feats, labels, want_dfeats)
         repeat = self._last_key == key
         self._last_key = key

@@ -130,6 +130,11 @@ def test_finetuner_fp8_path_against_bf16_path_and_oracle():
     ft8.refresh_operands(cast=True)
     assert ft8.f8["warm"] is False and float(ft8.f8["amax4"].abs().max()) == 0.0
     assert bool((ft8.f8["scale4"] > 0).all()) and not torch.equal(ft8.f8["scale4"], torch.ones_like(s_before))
+    # a second refresh with no step in between (load_params on resume, a layer skipped by layerdrop): nothing was measured, so the
+    # activation / gradient sites keep their delayed scales instead of dropping to 1 (small e5m2 gradients would flush to zero)
+    s_mid = ft8.f8["scale4"].clone(); s5_mid = ft8.f8["scale5"].clone()
+    ft8.refresh_operands(cast=True)
+    assert torch.equal(ft8.f8["scale4"], s_mid) and torch.equal(ft8.f8["scale5"], s5_mid) and not bool((ft8.f8["scale5"] == 1).all())
     o8b = ft8.forward_train(wav.cuda())
     d2 = (o8b - o8).abs()
     assert float(d2.max()) < 0.3, float(d2.max())                 # same input, same weights: only the (now delayed) scales may differ slightly

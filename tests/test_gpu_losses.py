@@ -26,6 +26,31 @@ def test_losses_and_grads_match_reference(seed):
     np.testing.assert_allclose(dlog.cpu().numpy(), G["glogits_%d" % seed], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_triplet_and_euclidean_losses_match_reference_and_differentiate(seed):
+    """custom_loss.py:32-74 through occ_pair_dist_loss: values vs the reference's own outputs (losses_eer.npz), gradients vs the
+    oracle's autograd; the losses take part in torch autograd like the reference's (shape [1])."""
+    from occm_amd.losses import custom_loss as cl
+    from oracle import losses_ref
+    n, e = CASES[seed]
+    emb = torch.randn(n, e, generator=torch.Generator().manual_seed(seed))
+    for name, fn, ref_fn, kw in (("triplet", cl.triplet_loss, losses_ref.triplet_loss, {}), ("euclid", cl.euclidean_distance_loss, losses_ref.euclidean_distance_loss, {}),
+                                 ("triplet_shut", cl.triplet_loss, losses_ref.triplet_loss, {"margin": -50.0})):
+        x = emb.clone().cuda().requires_grad_(True)
+        loss = fn(x, **kw)
+        assert tuple(loss.shape) == (1,)
+        if not kw:
+            np.testing.assert_allclose(loss.detach().cpu().numpy(), G["%s_%d" % (name, seed)], rtol=1e-5)
+        (loss * 0.7).sum().backward()
+        xr = emb.clone().requires_grad_(True)
+        lr = ref_fn(xr, **kw)
+        (lr * 0.7).sum().backward()
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), lr.detach().numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-7)
+    if "shut" in name:
+        assert float(loss) == 0.0 and float(x.grad.abs().max()) == 0.0
+
+
 def test_grouped_compactness_is_mean_of_group_values():
     from occm_amd import ops
     from oracle import losses_ref
