@@ -45,6 +45,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-overlap", action="store_true", help="no side-stream prefetch of the next batch's data stage (frozen: RawBoost + features; fine-tuned: RawBoost)")
     ap.add_argument("--fp8", action="store_true", help="not the headline: forward / input-gradient GEMMs of the transformer layers on the fp8 MFMA path (e4m3 / e5m2, "
                     "delayed per-tensor scaling), as BASELINE configs[4] asks for XLS-R-1B; weight gradients stay bf16")
+    ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the XLS-R gradients on the xGMI links (bf16 halves the 1.26 GB "
+                    "payload; sums are widened back into the f32 gradient buffer before Adam).  Default f32 = the exact sum")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous only (gloo, no GPU call): every rank reports world size and its shard of the "
                     "utterance groups, rank 0 prints them as one JSON line")
     return ap.parse_args(argv)
@@ -64,6 +66,10 @@ def launch_ranks(n, argv):
     output through and exit with their status.  Replaces nn.DataParallel's single process (oc_training.py:328)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # RCCL's collectives run as kernels of one workgroup per channel.  The hot GEMMs launch one 128-KiB-LDS workgroup per CU (228 of
+    # 256 CUs for the N = 1024 launches): 16 channels keep the all-reduce inside the CUs those grids leave free, instead of turning a
+    # one-round GEMM launch into two.  16 channels x ~20 GB/s still move a layer's 50 MB slice in well under its backward time.
+    env.setdefault("NCCL_MAX_NCHANNELS", "16")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
     return subprocess.run(cmd, env=env).returncode
@@ -290,7 +296,7 @@ def main():
         model.ssl_model.model.enable_fp8()
     model.train()
     trainer = OcTrainer(model, lr=1e-5, w_compact=wc, w_descr=wd, train_frontend=bool(finetune), rawboost_algo=rawboost,
-                        group_size=12 if bs % 12 == 0 else None, rank=rank)
+                        group_size=12 if bs % 12 == 0 else None, rank=rank, grad_wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
     wav, labels = synth_batch(bs, rank, dev)
     fe = model.ssl_model.model
 
@@ -387,7 +393,7 @@ def main():
                                        (", features of step i+1 computed on a side stream during step i's back-end" if overlap else "")),
                           "backend": ("fwd+bwd, f32 storage, bf16-MFMA GEMMs and weight gradients (f32 accumulate), dropout on, Adam lr=1e-5" if args.backend == "aasist"
                                       else "SE-ResNet34 fwd+bwd, f32 storage, bf16-MFMA convolutions and weight gradients (f32 accumulate), Adam lr=1e-5"),
-                          "gradient_exchange": "none (1 rank)" if world == 1 else "RCCL all-reduce of the flat f32 gradients, per transformer layer, overlapped with backward",
+                          "gradient_exchange": "none (1 rank)" if world == 1 else "RCCL all-reduce of the flat gradients (%s on the wire, f32 accumulation), per transformer layer, overlapped with backward; NCCL_MAX_NCHANNELS=%s" % (args.grad_wire, os.environ.get("NCCL_MAX_NCHANNELS", "default")),
                           "loss": "%.1f*compactness + %.1f*descriptiveness (%s)" % (wc, wd, "oc_training.py:380-381" if args.backend == "aasist" else "test_dataloader_v2.py:127"),
                           "final_loss_d": round(loss_d, 5), "gemm_src_sha16": gemm_source_sha()},
                "roofline": roof, "cpu_baseline": cpu}

@@ -183,6 +183,10 @@ typedef struct occ_gemm_tn_desc {
      * calls that share one workspace must be ordered on one stream.  NULL / 0: the atomics path is used.  268 MB covers every
      * weight of XLS-R-300M/1B at any batch size (256 workgroups x 256 KiB slabs + tickets).                                        */
     void* workspace; int64_t workspace_bytes;
+    /* n_groups > 1: that many independent products in one launch (the weight gradient of a grouped Conv1d: group g uses
+     * A + g*a_group_stride, B + g*b_group_stride, C + g*c_group_stride, strides in elements); bf16 operands / bf16 MFMA only,
+     * N1 >= 64, colsum must be NULL (sum the whole A once with occ_colsum).  0 / 1: one product.                                  */
+    int64_t n_groups, a_group_stride, b_group_stride, c_group_stride;
 } occ_gemm_tn_desc;
 int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream);
 /* Two weight gradients with the same reduction rows M (out-proj with qkv, fc2 with fc1 of one transformer layer) in ONE launch when both
@@ -394,6 +398,19 @@ int occ_weight_norm_bwd(const float* v, const float* g, const float* norms, cons
 /* dx_bf16 (optional): a bf16 copy of dx for the next input-gradient GEMMs.                                             */
 int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16,
                       float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, float* scratch, int64_t scratch_floats, void* stream);
+/* The keep-mask of occ_dropout_ex(generate = 1) on its own: mask[i] = 1 with probability 1 - p, Philox4x32-10 counter (i / 4, stream_id),
+ * key seed -- the same bytes occ_dropout_ex writes for the same (n, p, seed, stream_id).                                          */
+int occ_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
+/* The same attention core with fairseq's attention_dropout (MultiheadAttention: attn_probs = dropout(softmax(.)), live in the
+ * reference because XLS-R stays in train mode: oc_training.py:352, sslassist.py:20-29): keep is a u8 mask [B*H, T, Tp], Tp = T rounded
+ * up to a multiple of 4, 4-byte aligned (non-zero = keep; draw it with occ_dropout_ex(generate = 1) or pass your own), p the drop
+ * probability.  bf16 only, head_dim 64 or 80, any T; lse (f32 [B*H, T], may be NULL) is the log-sum-exp of the UNdropped scores.
+ * The backward takes the same mask.                                                                                             */
+int occ_attention_dropout(const void* qkv, void* out, int64_t B, int64_t T, int64_t H, int64_t hd, int64_t ld_qkv, int64_t ld_out,
+                          float scale, float* lse, const uint8_t* keep, float p, void* stream);
+int occ_attention_bwd_dropout(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T,
+                              int64_t H, int64_t hd, int64_t ld_qkv, int64_t ld_o, float scale, float* dq_accum, const uint8_t* keep,
+                              float p, void* stream);
 /* dq|dk|dv (bf16 [B*T, 3D], same layout as qkv) of softmax(scale q.k^T) v given o (forward output), dout and the forward's lse.
  * head_dim 64 or 80, any T.  T > 256 needs dq_accum: caller-owned f32 scratch [B*T, H*hd] (16-byte aligned) in which the key blocks
  * of a head meet; it may be NULL for T <= 256.                                                                   */

@@ -5,7 +5,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
+# OCC_LIB (developer switch): another build of the same ABI next to the default one, for A/B timing of kernel variants on one device
+LIB_PATH = os.path.join(_HERE, os.environ.get("OCC_LIB") or "libocc_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "occ_hip.h")
 
 OCC_F32, OCC_BF16, OCC_F64, OCC_F32_AS_BF16, OCC_AF32_WBF16, OCC_FP8_E4M3, OCC_FP8_E5M2 = 0, 1, 2, 3, 4, 5, 6
@@ -42,7 +43,8 @@ class GemmTnDesc(ctypes.Structure):
                 ("b_seg_stride", ctypes.c_int64),
                 ("C", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("alpha", ctypes.c_float), ("colsum", ctypes.c_void_p),
                 ("a_dtype", ctypes.c_int), ("b_dtype", ctypes.c_int), ("compute", ctypes.c_int),
-                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64)]
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
+                ("n_groups", ctypes.c_int64), ("a_group_stride", ctypes.c_int64), ("b_group_stride", ctypes.c_int64), ("c_group_stride", ctypes.c_int64)]
 
 
 _P = ctypes.c_void_p

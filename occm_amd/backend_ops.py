@@ -42,8 +42,11 @@ def tn_workspace():
     return _TN_WS[key]
 
 
-def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsum_out=None, a_bf16=False, b_bf16=False, bf16_mfma=False):
+def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsum_out=None, a_bf16=False, b_bf16=False, bf16_mfma=False, groups=None):
+    """groups = (n_groups, a_stride, b_stride, c_stride) in elements: that many independent products in one launch (grouped conv)."""
     d = GemmTnDesc()
+    if groups is not None:
+        d.n_groups, d.a_group_stride, d.b_group_stride, d.c_group_stride = [int(x) for x in groups]
     if a_bf16 and b_bf16 and bf16_mfma and N1 % 256 == 0 and N2 % 256 == 0 and M >= 1024:
         ws = tn_workspace()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()

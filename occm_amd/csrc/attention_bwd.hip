@@ -44,11 +44,14 @@ template <int HD> __device__ __forceinline__ unsigned ab_off(int r, int c) {
     return (unsigned)(r * AbCfg<HD>::ROWB + c * 16);
 }
 
-template <int HD>
+// DROP (attention_dropout, see occ_attention_dropout): with O = (P o keep / (1-p)) V the forward's O already carries the mask, so
+// delta = rowsum(dO o O) is unchanged; dV uses the dropped probabilities, dP is masked and scaled the same way before dS = P o (dP - delta).
+template <int HD, bool DROP = false>
 __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ o,
                                                                const unsigned short* __restrict__ dout, const float* __restrict__ lse,
                                                                unsigned short* __restrict__ dqkv, float* __restrict__ dq_accum, int Tn, int H,
-                                                               long long ld_qkv, long long ld_o, float scale) {
+                                                               long long ld_qkv, long long ld_o, float scale,
+                                                               const unsigned char* __restrict__ keep = nullptr, int Tp = 0, float inv_keep = 1.f) {
     using C = AbCfg<HD>;
     constexpr int KS = C::KS, DT = C::DT, CH = C::CH, ROWB = C::ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -241,8 +244,14 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
                 for (int r = 0; r < 4; ++r) {
                     const int ql = qt * 16 + g * 4 + r;
                     const float p = key < nkeys ? __builtin_amdgcn_exp2f(sacc[r] * c2 - lq[qt][r]) : 0.f;
-                    pv[qt][r] = p;
-                    dsv[qt][r] = p * (dpacc[r] - dq_[qt][r]);
+                    float pd = p, dpd = dpacc[r];
+                    if constexpr (DROP) {
+                        const int qg = q0 + ql < Tn ? q0 + ql : Tn - 1, kg = key < nkeys ? key0 + key : Tn - 1;
+                        const float mk = keep[((size_t)bh * Tn + qg) * Tp + kg] ? inv_keep : 0.f;
+                        pd *= mk; dpd *= mk;
+                    }
+                    pv[qt][r] = pd;
+                    dsv[qt][r] = p * (dpd - dq_[qt][r]);
                     dSs[ql * AB_DS_STRIDE + key] = f32_to_bf16_bits(dsv[qt][r]);
                 }
             }
@@ -320,17 +329,18 @@ __global__ void attention_dq_finish_kernel(const float* __restrict__ acc, unsign
     }
 }
 
-template <int HD>
+template <int HD, bool DROP = false>
 int launch_attention_bwd2(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* dq_accum, int64_t B, int64_t T, int64_t H,
-                          int64_t ld_qkv, int64_t ld_o, float scale, hipStream_t s) {
+                          int64_t ld_qkv, int64_t ld_o, float scale, hipStream_t s, const unsigned char* keep = nullptr, float p = 0.f) {
     using C = AbCfg<HD>;
     const size_t shm = (size_t)AB_KEYS * C::ROWB + 4 * 32 * C::ROWB + 2 * 32 * AB_DS_STRIDE * 2 + 128 * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)attention_bwd2_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipError_t e = hipFuncSetAttribute((const void*)attention_bwd2_kernel<HD, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) { occ_set_error("occ_attention_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
     const int64_t nkb = occ_cdiv(T, AB_KEYS);
     if (nkb > 1 && hipMemsetAsync(dq_accum, 0, (size_t)(B * T * H * HD) * sizeof(float), s) != hipSuccess) { occ_set_error("occ_attention_bwd: memset failed"); return OCC_ELAUNCH; }
-    hipLaunchKernelGGL(attention_bwd2_kernel<HD>, dim3((unsigned)(B * H), (unsigned)nkb), dim3(512), shm, s, (const unsigned short*)qkv, (const unsigned short*)o,
-                       (const unsigned short*)dout, lse, (unsigned short*)dqkv, dq_accum, (int)T, (int)H, (long long)ld_qkv, (long long)ld_o, scale);
+    hipLaunchKernelGGL((attention_bwd2_kernel<HD, DROP>), dim3((unsigned)(B * H), (unsigned)nkb), dim3(512), shm, s, (const unsigned short*)qkv, (const unsigned short*)o,
+                       (const unsigned short*)dout, lse, (unsigned short*)dqkv, dq_accum, (int)T, (int)H, (long long)ld_qkv, (long long)ld_o, scale, keep,
+                       (int)((T + 3) / 4 * 4), 1.0f / (1.0f - p));
     if (nkb > 1) {
         long long blocks = occ_cdiv(B * T * (H * HD / 4), 256);
         if (blocks > 4096) blocks = 4096;
@@ -340,6 +350,20 @@ int launch_attention_bwd2(const void* qkv, const void* o, const void* dout, cons
 }
 
 }  // namespace
+
+extern "C" int occ_attention_bwd_dropout(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H, int64_t hd,
+                                         int64_t ld_qkv, int64_t ld_o, float scale, float* dq_accum, const uint8_t* keep, float p, void* stream) {
+    OCC_CHECK_ARG(qkv && o && dout && lse && dqkv && keep, "occ_attention_bwd_dropout: null pointer");
+    OCC_CHECK_ARG((hd == 64 || hd == 80) && T >= 1 && B >= 1 && H >= 1 && B * H < (1ll << 31) && T < (1ll << 24), "occ_attention_bwd_dropout: head_dim must be 64 or 80 (T=%ld hd=%ld)", (long)T, (long)hd);
+    OCC_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_qkv >= 3 * H * hd && ld_o >= H * hd && p >= 0.f && p < 1.f, "occ_attention_bwd_dropout: leading dimensions / p");
+    OCC_CHECK_ARG(T <= AB_KEYS || (dq_accum && ((uintptr_t)dq_accum & 15) == 0), "occ_attention_bwd_dropout: T > %d needs the f32 dq accumulator [B*T, H*hd]", AB_KEYS);
+    int rc;
+    if (hd == 64) rc = launch_attention_bwd2<64, true>(qkv, o, dout, lse, dqkv, dq_accum, B, T, H, ld_qkv, ld_o, scale, (hipStream_t)stream, (const unsigned char*)keep, p);
+    else rc = launch_attention_bwd2<80, true>(qkv, o, dout, lse, dqkv, dq_accum, B, T, H, ld_qkv, ld_o, scale, (hipStream_t)stream, (const unsigned char*)keep, p);
+    if (rc != OCC_OK) return rc;
+    OCC_LAUNCH_CHECK("occ_attention_bwd_dropout");
+    return OCC_OK;
+}
 
 extern "C" int occ_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H, int64_t hd,
                                  int64_t ld_qkv, int64_t ld_o, float scale, float* dq_accum, void* stream) {

@@ -393,9 +393,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
 // 10 chunks of 16 B (a 160-byte row stride is conflict-free for ds_read_b128 as it stands, no swizzle), O has 5 column blocks.
 typedef __attribute__((ext_vector_type(4))) short att_s16x4;
 typedef __attribute__((address_space(3))) att_s16x4 att_lds_s16x4;
-template <int HD>
+// DROP: fairseq's attention_dropout (MultiheadAttention: attn_probs = dropout(softmax(.))): the keep-mask is a u8 tensor [B*H, T, Tp]
+// (Tp = T rounded up to 4, drawn by occ_dropout_ex or injected by a test); the normaliser l stays the sum of the UNdropped
+// probabilities, the P.V product uses p * keep / (1 - p_drop).
+template <int HD, bool DROP = false>
 __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
-                                                                 int Tn, int H, long long ld_qkv, long long ld_out, float scale, float* __restrict__ lse) {
+                                                                 int Tn, int H, long long ld_qkv, long long ld_out, float scale, float* __restrict__ lse,
+                                                                 const unsigned char* __restrict__ keep = nullptr, int Tp = 0, float inv_keep = 1.f) {
     constexpr int NP = 4, NK = NP * 32;
     constexpr int CH = HD / 8, KS = (HD + 31) / 32, NDT = HD / 16;     // 16-byte chunks per row, QK^T k-steps, 16-column blocks of O
     __shared__ uint4 Ks[NK * CH];
@@ -474,6 +478,15 @@ __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned
         sum += __shfl_xor(sum, 32, 64);
         l_run = l_run * alpha + sum;
         m_run = m_new;
+        if constexpr (DROP) {
+            const unsigned char* krow = keep + ((size_t)bh * Tn + qld) * Tp + k0 + g * 4;
+#pragma unroll
+            for (int t = 0; t < 2 * NP; ++t) {
+                const unsigned m4 = k0 + t * 16 + g * 4 < Tn ? *reinterpret_cast<const unsigned*>(krow + t * 16) : 0u;      // four consecutive keys of this lane's query
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[t][r] = ((m4 >> (8 * r)) & 0xffu) ? sc[t][r] * inv_keep : 0.f;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                        // O rows are queries 4g + r; their factor lives in the lane with fr == 4g + r
             const float a_q = __shfl(alpha, g * 4 + r, 64);
@@ -707,6 +720,25 @@ int occ_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const
     else { occ_set_error("occ_conv0_ln_gelu: out dtype must be f32 or bf16"); return OCC_EUNSUPPORTED; }
 #undef OCC_C0_LAUNCH
     OCC_LAUNCH_CHECK("occ_conv0_ln_gelu");
+    return OCC_OK;
+}
+
+int occ_attention_dropout(const void* qkv, void* out, int64_t B, int64_t T, int64_t H, int64_t hd, int64_t ld_qkv, int64_t ld_out, float scale, float* lse,
+                          const uint8_t* keep, float p, void* stream) {
+    OCC_CHECK_ARG(qkv && out && keep, "occ_attention_dropout: null pointer");
+    OCC_CHECK_ARG(B >= 1 && T >= 1 && H >= 1 && (hd == 64 || hd == 80) && T <= (1 << 20), "occ_attention_dropout: head_dim must be 64 or 80");
+    OCC_CHECK_ARG(ld_qkv >= 3 * H * hd && ld_out >= H * hd && ld_qkv % 8 == 0 && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "occ_attention_dropout: leading dimensions / alignment");
+    OCC_CHECK_ARG(p >= 0.f && p < 1.f && (reinterpret_cast<uintptr_t>(keep) & 3) == 0, "occ_attention_dropout: p must be in [0, 1), the mask 4-byte aligned");
+    const int Tp = (int)((T + 3) / 4 * 4);
+    const dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (hd == 64)
+        hipLaunchKernelGGL((attention_mfma_long_kernel<64, true>), grid, block, 0, s, (const unsigned short*)qkv, (unsigned short*)out, (int)T, (int)H, (long long)ld_qkv,
+                           (long long)ld_out, scale, lse, (const unsigned char*)keep, Tp, 1.0f / (1.0f - p));
+    else
+        hipLaunchKernelGGL((attention_mfma_long_kernel<80, true>), grid, block, 0, s, (const unsigned short*)qkv, (unsigned short*)out, (int)T, (int)H, (long long)ld_qkv,
+                           (long long)ld_out, scale, lse, (const unsigned char*)keep, Tp, 1.0f / (1.0f - p));
+    OCC_LAUNCH_CHECK("occ_attention_dropout");
     return OCC_OK;
 }
 

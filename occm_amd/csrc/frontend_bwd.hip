@@ -416,6 +416,23 @@ __global__ void dropout_ex_kernel(const TX* __restrict__ x, TY* __restrict__ y, 
     }
 }
 
+// The keep-mask alone, bit-identical to what dropout_ex_kernel(gen = 1) draws for the same (n, p, seed, sid): the attention-dropout
+// mask [B*H, T, Tp] is consumed inside the attention kernels, there is no tensor to apply it to here.
+__global__ void dropout_mask_kernel(unsigned char* __restrict__ mask, long long n, float p, uint64_t seed, uint64_t sid) {
+    const long long nq = (n + 3) / 4;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { fb_philox_r(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        unsigned w = 0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) w |= (((float)c[h] * (1.0f / 4294967296.0f)) >= p ? 1u : 0u) << (8 * h);
+        if (q * 4 + 3 < n && ((uintptr_t)mask & 3) == 0) *reinterpret_cast<unsigned*>(mask + q * 4) = w;
+        else for (int h = 0; h < 4; ++h) if (q * 4 + h < n) mask[q * 4 + h] = (unsigned char)((w >> (8 * h)) & 1u);
+    }
+}
+
 // out[omap(r)][c] = bf16(dy[r][c] * gelu'(u[r][c]))   (gradient through the positional conv's GELU, written into the padded buffer)
 __global__ void gelu_bwd_rows_kernel(const float* __restrict__ dy, const unsigned short* __restrict__ u, unsigned short* __restrict__ out, RowMapI omap,
                                      long long rows, int C) {
@@ -789,6 +806,16 @@ int occ_dropout_ex(const void* x, int x_dtype, void* y, int y_dtype, uint8_t* ma
     else OCC_DX(unsigned short, unsigned short);
 #undef OCC_DX
     OCC_LAUNCH_CHECK("occ_dropout_ex");
+    return OCC_OK;
+}
+
+int occ_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
+    OCC_CHECK_ARG(mask && n >= 0 && p >= 0.f && p < 1.f, "occ_dropout_mask: bad argument");
+    if (n == 0) return OCC_OK;
+    long long blocks = occ_cdiv(occ_cdiv(n, 4), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (long long)n, p, seed, stream_id);
+    OCC_LAUNCH_CHECK("occ_dropout_mask");
     return OCC_OK;
 }
 

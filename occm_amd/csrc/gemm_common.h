@@ -214,9 +214,14 @@ template <int NJ, bool HASB, bool GELU, bool HASR, bool CBF, int AUXM>
 __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int lane, unsigned char* lds_wave, int rows) {
     static_assert(NJ % 2 == 0, "row epilogue works on pairs of 16-row blocks");
     constexpr int RS = 272;
+    constexpr int NCH = NJ / 2;
     const int fr = lane & 15, fq = lane >> 4;
     const bool plain_c = a.cmap.rpl == 0 && a.cmap.rpb >= a.M, plain_r = !HASR || (a.rmap.rpl == 0 && a.rmap.rpb >= a.M);
     const float al = a.alpha * (a.dq_a ? *a.dq_a : 1.f) * (a.dq_w ? *a.dq_w : 1.f);       // (1.0 for the bf16 path: the product below is exact)
+    // Side-tensor reads (the saved pre-activation of the GELU' form, the f32 residual) are issued for a whole 32-row chunk BEFORE the
+    // chunk's LDS round trip and one chunk AHEAD of their use, from row / column indices clamped into the matrix so that no load sits
+    // behind a bounds branch: behind `if (row valid)` every one of a lane's 16-32 loads was its own HBM round trip in program order
+    // (out-proj at bs 64 with cold operands: 82 us, of which the K loop is 18).
     if constexpr (CBF && !HASR) {
         // bf16 results (and the bf16 side tensor): EIGHT columns per lane, a row per 8 lanes -- 16-byte stores, eight rows per instruction
         const int rr = lane >> 3, cc = lane & 7;
@@ -224,8 +229,18 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
         f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = b0;
         const bool whole = n + 8 <= a.N;
         if (HASB && n < a.N) { b0 = *reinterpret_cast<const f32x4*>(a.bias + n); if (whole) b1 = *reinterpret_cast<const f32x4*>(a.bias + n + 4); }
+        const long long nld = n + 8 <= a.N ? n : (a.N >= 8 ? a.N - 8 : 0);        // a column group that lies inside the row (its values are unused when n is not whole)
+        uint4 ux[4];                               // this chunk's four side-tensor vectors; slot k is refilled for the next chunk right after its use
+        auto load_aux = [&](const int ch, const int k) {
+            long long m = mrow0 + ch * 32 + k * 8 + rr; if (m > a.M - 1) m = a.M - 1;
+            return *reinterpret_cast<const uint4*>(a.aux + (plain_c ? m * a.cmap.rstride : row_off(a.cmap, m)) + nld);
+        };
+        if (AUXM == 2 && a.N >= 8) {
 #pragma unroll
-        for (int ch = 0; ch < NJ / 2; ++ch) {
+            for (int k = 0; k < 4; ++k) ux[k] = load_aux(0, k);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -236,6 +251,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
                 const int rloc = k * 8 + rr;
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(lds_wave + rloc * RS + cc * 32), v1 = *reinterpret_cast<const f32x4*>(lds_wave + rloc * RS + cc * 32 + 16);
                 const long long m = mrow0 + ch * 32 + rloc;
+                uint4 u = make_uint4(0, 0, 0, 0);
+                if (AUXM == 2 && a.N >= 8) { u = ux[k]; if (ch + 1 < NCH) ux[k] = load_aux(ch + 1, k); }
                 if (m >= a.M || n >= a.N || ch * 32 + rloc >= rows) continue;
                 const long long coff = (plain_c ? m * a.cmap.rstride : row_off(a.cmap, m)) + n;
                 v0 = v0 * al; v1 = v1 * al;
@@ -251,7 +268,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
                     else { *reinterpret_cast<uint2*>(a.aux + coff) = make_uint2(o.x, o.y); }          // N % 4 == 0: a ragged last group is 4 columns
                 }
                 if (AUXM == 2) {
-                    const uint4 u = whole ? *reinterpret_cast<const uint4*>(a.aux + coff) : make_uint4(reinterpret_cast<const uint2*>(a.aux + coff)->x, reinterpret_cast<const uint2*>(a.aux + coff)->y, 0, 0);
+                    if (!whole) { const uint2 t = *reinterpret_cast<const uint2*>(a.aux + coff); u = make_uint4(t.x, t.y, 0, 0); }       // ragged last column group (rare): its own load
                     const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[2 * e] *= gelu_grad(bf16_bits_to_f32((unsigned short)(w[e] & 0xffff))); v[2 * e + 1] *= gelu_grad(bf16_bits_to_f32((unsigned short)(w[e] >> 16))); }
@@ -271,8 +288,18 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
     const long long n = ncol0 + cc * 4;
     f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (HASB && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+    const long long nld = n < a.N ? n : 0;                      // N % 4 == 0: a lane's four columns are inside the row or all outside it
+    f32x4 rx[HASR ? 8 : 1];                        // this chunk's eight residual vectors; slot k is refilled for the next chunk right after its use
+    auto load_res = [&](const int ch, const int k) {
+        long long m = mrow0 + ch * 32 + k * 4 + rr; if (m > a.M - 1) m = a.M - 1;
+        return *reinterpret_cast<const f32x4*>(a.R + ((plain_r ? m * a.rmap.rstride : row_off(a.rmap, m)) + nld) * 4);
+    };
+    if constexpr (HASR) {
 #pragma unroll
-    for (int ch = 0; ch < NJ / 2; ++ch) {
+        for (int k = 0; k < 8; ++k) rx[k] = load_res(0, k);
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -282,6 +309,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
         for (int k = 0; k < 8; ++k) {
             f32x4 v = *reinterpret_cast<const f32x4*>(lds_wave + (k * 4 + rr) * RS + cc * 16);
             const long long m = mrow0 + ch * 32 + k * 4 + rr;
+            f32x4 rv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (HASR) { rv = rx[k]; if (ch + 1 < NCH) rx[k] = load_res(ch + 1, k); }
             if (m >= a.M || n >= a.N || ch * 32 + k * 4 + rr >= rows) continue;
             const long long coff = (plain_c ? m * a.cmap.rstride : row_off(a.cmap, m)) + n;
             v = v * al;
@@ -298,7 +327,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
                 v[2] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y & 0xffff))); v[3] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y >> 16)));
             }
             if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
-            if (HASR) v += *reinterpret_cast<const f32x4*>(a.R + ((plain_r ? m * a.rmap.rstride : row_off(a.rmap, m)) + n) * 4);
+            if (HASR) v += rv;
             if (CBF) {
                 uint2 o;
                 o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);

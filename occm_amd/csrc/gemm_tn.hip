@@ -28,6 +28,8 @@ struct TnArgs {
     int t1, t2;               // tiles along N1 / N2 (grid is 1-D: XCD-aware order, see tn_block)
     float* colsum;            // optional: colsum[n1] += alpha * sum_m A[m, n1] (bias gradient), done by the n2-tile-0 workgroups
     long long m_first;        // gemm_tn_dma_kernel: first reduction row of this launch (the rows before it were done by gemm_tn_p8)
+    int ngroups;              // gemm_tn_dma_kernel: independent products (grouped conv: one per channel group) folded into the grid
+    long long a_gs, b_gs, c_gs;   // element strides between the groups' A / B / C
 };
 
 __device__ __forceinline__ float4 ld4_bf16(const unsigned short* p) {
@@ -39,10 +41,13 @@ __device__ __forceinline__ float4 ld4_bf16(const unsigned short* p) {
 // logical ids ordered split-major, so every tile that reads one row range sits on the same XCD and that range crosses the
 // Infinity-Cache -> L2 boundary once instead of once per XCD (measured on the 88704 x 64 x 384 conv weight gradient: the
 // un-mapped grid moved ~8x the operand bytes into the L2s and ran at 1 TB/s of unique operand bytes).
-__device__ __forceinline__ void tn_block(const TnArgs& a, int& bx, int& by, int& bz) {
+__device__ __forceinline__ int tn_lid() {
     const int total = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = total >> 3, r8 = total & 7;
-    const int l = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+}
+__device__ __forceinline__ void tn_block(const TnArgs& a, int& bx, int& by, int& bz) {
+    const int l = tn_lid();
     bx = l % a.t1; by = (l / a.t1) % a.t2; bz = l / (a.t1 * a.t2);
 }
 
@@ -279,7 +284,13 @@ constexpr int TD = 128, SLD = 64;
 template <int KG>
 __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_tn_dma_kernel(const TnArgs a) {
     __shared__ uint4 lds_all[KG * 2 * SLD * 16];          // per group: A slab (64 rows x 16 chunks), then B slab
-    int bx, by, bz; tn_block(a, bx, by, bz);
+    int bx, by, bz;
+    long long grp = 0;                                    // grouped products: the group is the slowest index of the (XCD-contiguous) block id
+    if (a.ngroups > 1) {
+        const int l = tn_lid(), per = (int)(gridDim.x / a.ngroups), l2 = l % per;
+        grp = l / per;
+        bx = l2 % a.t1; by = (l2 / a.t1) % a.t2; bz = l2 / (a.t1 * a.t2);
+    } else tn_block(a, bx, by, bz);
     const long long n1_0 = (long long)bx * TD, n2_0 = (long long)by * TD;
     const long long wg_begin = a.m_first + (long long)bz * a.rows_per_split;
     const long long wg_end = wg_begin + a.rows_per_split < a.M ? wg_begin + a.rows_per_split : a.M;
@@ -292,16 +303,16 @@ __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(4, 4))
     uint4* lds = lds_all + kg * 2 * SLD * 16;
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
-    long long bseg_off = n2_0;
-    if (a.nseg > 1) { const long long sg = n2_0 / a.seg_len; bseg_off = sg * a.seg_stride + (n2_0 - sg * a.seg_len); }
     // staging: DMA ii = pass * 4 + wave covers rows 4*ii .. 4*ii+3; lane -> (row_local = lane >> 4, 16-byte position p = lane & 15)
     const int rl = lane >> 4, p16 = lane & 15;
     // rows 4*ii + rl of this lane have (row & 7) = (4*wave + rl) & 7 for every pass: one swizzled column offset per operand
     const int cb = (p16 >> 1) ^ ((4 * wave + rl) & 7);
     long long c1 = n1_0 + cb * 16 + (p16 & 1) * 8; if (c1 > a.N1 - 8) c1 = a.N1 - 8;           // columns past N1 / N2 feed outputs that are never stored
-    long long c2 = cb * 16 + (p16 & 1) * 8; if (n2_0 + c2 > a.N2 - 8) c2 = a.N2 - 8 - n2_0;
-    const unsigned short* Ap = (const unsigned short*)a.A + c1;
-    const unsigned short* Bp = (const unsigned short*)a.B + bseg_off + c2;
+    long long c2 = n2_0 + cb * 16 + (p16 & 1) * 8; if (c2 > a.N2 - 8) c2 = a.N2 - 8;
+    // K-segmented B (conv windows): the lane's eight columns lie inside one segment (seg_len % 8 == 0); a tile may span several segments
+    if (a.nseg > 1) { const long long sg = c2 / a.seg_len; c2 = sg * a.seg_stride + (c2 - sg * a.seg_len); }
+    const unsigned short* Ap = (const unsigned short*)a.A + grp * a.a_gs + c1;
+    const unsigned short* Bp = (const unsigned short*)a.B + grp * a.b_gs + c2;
     const bool plain = a.amap.rpl == 0 && a.bmap.rpl == 0 && a.amap.rpb >= a.M && a.bmap.rpb >= a.M;     // plain matrices: offset = m * row_stride
     f32x4 acc[4][4];
 #pragma unroll
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int ib = 0; ib < 4; ++ib) {
             const long long n2 = n2_0 + wj * 64 + ib * 16 + g * 4;
             if (n2 >= a.N2) continue;                       // N2 % 4 == 0
-            float* cp = a.C + n1 * a.ldc + n2;
+            float* cp = a.C + grp * a.c_gs + n1 * a.ldc + n2;
             if (a.atomic) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) atomicAdd(cp + e, acc[ia][ib][e] * a.alpha);
@@ -522,15 +533,17 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
     a.A = d->A; a.amap = to_rowmap(d->a_map);
     a.B = d->B; a.bmap = to_rowmap(d->b_map); a.nseg = nseg; a.seg_len = seg_len; a.seg_stride = d->b_seg_stride;
     a.C = (float*)d->C; a.ldc = d->ldc; a.alpha = d->alpha; a.colsum = (float*)d->colsum; a.atomic = 1; a.m_first = 0;
+    const long long ngr = d->n_groups > 1 ? d->n_groups : 1;
+    a.ngroups = (int)ngr; a.a_gs = ngr > 1 ? d->a_group_stride : 0; a.b_gs = ngr > 1 ? d->b_group_stride : 0; a.c_gs = ngr > 1 ? d->c_group_stride : 0;
     const bool abf0 = d->a_dtype == OCC_BF16, bbf0 = d->b_dtype == OCC_BF16;
     static const int dma_env = getenv("OCC_TN_DMA") ? atoi(getenv("OCC_TN_DMA")) : 1;
-    if (dma_env && d->compute == OCC_BF16 && abf0 && bbf0 && d->N1 % 8 == 0 && d->N2 % 8 == 0 && d->N1 >= 128 && d->N2 >= 128 && d->M >= 256 &&
-        (nseg == 1 || seg_len % TD == 0) && d->ldc % 4 == 0 && ((uintptr_t)d->C & 15) == 0 &&
+    if (dma_env && d->compute == OCC_BF16 && abf0 && bbf0 && d->N1 % 8 == 0 && d->N2 % 8 == 0 && d->N1 >= 64 && d->N2 >= 128 && d->M >= 256 &&
+        (nseg == 1 || seg_len % 8 == 0) && (ngr == 1 || (d->a_group_stride % 8 == 0 && d->b_group_stride % 8 == 0 && d->c_group_stride % 4 == 0 && !d->colsum)) && d->ldc % 4 == 0 && ((uintptr_t)d->C & 15) == 0 &&
         d->a_map.row_stride % 8 == 0 && d->a_map.batch_stride % 8 == 0 && d->a_map.line_stride % 8 == 0 &&
         d->b_map.row_stride % 8 == 0 && d->b_map.batch_stride % 8 == 0 && d->b_map.line_stride % 8 == 0 && (nseg == 1 || d->b_seg_stride % 8 == 0)) {
         // Large outputs (multiples of 256 both ways, one K segment): the 256x256 eight-phase kernel on all whole 64-row K-tiles, reduction
         // pieces joined through workspace slabs instead of atomics; what is left (M % 64 rows) goes through the kernel below.
-        if (nseg == 1) {
+        if (nseg == 1 && ngr == 1 && d->N1 >= 128) {
             const long long rows64 = d->M - d->M % 64;
             const int r = occ_tn_p8_try(rows64, d->N1, d->N2, d->A, a.amap, d->B, a.bmap, a.C, a.ldc, a.alpha, d->workspace, d->workspace_bytes,
                                         max_row_off(d->a_map, d->M) + d->N1, max_row_off(d->b_map, d->M) + d->N2, (hipStream_t)stream);
@@ -554,20 +567,34 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
         static const int kg_env = getenv("OCC_TN_KG") ? atoi(getenv("OCC_TN_KG")) : 0;
         static const long long dma_target = getenv("OCC_TN_DMA_TARGET") ? atoll(getenv("OCC_TN_DMA_TARGET")) : 0;
         const int KGv = kg_env == 1 || kg_env == 2 || kg_env == 4 ? kg_env : (d->M <= 65536 ? 4 : 1);
-        long long sp = occ_cdiv(dma_target > 0 ? dma_target : (KGv == 1 ? 512 : 2 * cu_count_tn() / KGv * 1), u1 * u2);
+        long long sp = occ_cdiv(dma_target > 0 ? dma_target : (KGv == 1 ? 512 : 2 * cu_count_tn() / KGv * 1), u1 * u2 * ngr);
         const long long msp = d->M / (256 * KGv);
         if (sp > msp) sp = msp;
         if (sp < 1) sp = 1;
         a.rows_per_split = occ_cdiv(occ_cdiv(d->M, sp), SLD) * SLD;
         sp = occ_cdiv(d->M, a.rows_per_split);
         a.t1 = (int)u1; a.t2 = (int)u2; a.atomic = sp > 1;
-        OCC_CHECK_ARG(u1 * u2 * sp < (1ll << 30), "occ_gemm_tn: output too large");
-        const dim3 grid((unsigned)(u1 * u2 * sp));
+        OCC_CHECK_ARG(u1 * u2 * sp * ngr < (1ll << 30), "occ_gemm_tn: output too large");
+        const dim3 grid((unsigned)(u1 * u2 * sp * ngr));
         if (KGv == 4) hipLaunchKernelGGL(gemm_tn_dma_kernel<4>, grid, dim3(1024), 0, (hipStream_t)stream, a);
         else if (KGv == 2) hipLaunchKernelGGL(gemm_tn_dma_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(gemm_tn_dma_kernel<1>, grid, dim3(THREADS), 0, (hipStream_t)stream, a);
         if (a.colsum) launch_colsum_bf16_vec((const unsigned short*)a.A, a.amap, a.M, a.N1, a.colsum, a.alpha, (hipStream_t)stream);
         OCC_LAUNCH_CHECK("occ_gemm_tn");
+        return OCC_OK;
+    }
+    if (ngr > 1) {                               // grouped, but not the LDS-DMA kernel's case (short reductions, f32 operands ...): one product per group
+        OCC_CHECK_ARG(!d->colsum, "occ_gemm_tn: grouped products take no colsum (sum the whole A once with occ_colsum)");
+        const long long ea = d->a_dtype == OCC_BF16 ? 2 : 4, eb = d->b_dtype == OCC_BF16 ? 2 : 4;
+        for (long long g = 0; g < ngr; ++g) {
+            occ_gemm_tn_desc one = *d;
+            one.n_groups = 1;
+            one.A = (const char*)d->A + g * d->a_group_stride * ea;
+            one.B = (const char*)d->B + g * d->b_group_stride * eb;
+            one.C = (float*)d->C + g * d->c_group_stride;
+            const int rc = occ_gemm_tn(&one, stream);
+            if (rc != OCC_OK) return rc;
+        }
         return OCC_OK;
     }
     const long long t1 = occ_cdiv(d->N1, TT), t2 = occ_cdiv(d->N2, TT);
@@ -605,6 +632,11 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
 int occ_colsum(const void* A, int a_dtype, const occ_rowmap* a_map, int64_t M, int64_t N, float* out, float alpha, void* stream) {
     OCC_CHECK_ARG(A && a_map && out && M >= 1 && N >= 1 && a_map->rows_per_batch >= 1, "occ_colsum: bad argument");
     OCC_CHECK_ARG(a_dtype == OCC_F32 || a_dtype == OCC_BF16, "occ_colsum: A must be f32 or bf16");
+    if (a_dtype == OCC_BF16 && N % 8 == 0 && ((uintptr_t)A & 15) == 0 && a_map->row_stride % 8 == 0 && a_map->batch_stride % 8 == 0 && a_map->line_stride % 8 == 0) {
+        launch_colsum_bf16_vec((const unsigned short*)A, to_rowmap(*a_map), M, N, out, alpha, (hipStream_t)stream);      // 16-byte loads
+        OCC_LAUNCH_CHECK("occ_colsum");
+        return OCC_OK;
+    }
     long long split = occ_cdiv(M, 512);
     if (split > 256) split = 256;
     const long long rps = occ_cdiv(M, split);

@@ -612,6 +612,24 @@ class XlsrFineTuner(XlsrFrontend):
     def _drop_bwd(self, site, dy, dx, p):
         ops.dropout_ex(dy, dx, self.masks[site], p, generate=False)
 
+    def _att_keep(self, i, B, T):
+        """Keep-mask u8 [B*H, T, Tp] (Tp = T rounded up to 4) of layer i's attention probabilities: injected as [B,H,T,T] by a test, or
+        drawn on the device (Philox keyed by drop_seed, step and the site id, like every other dropout site)."""
+        import zlib
+        site, H = "l%d.att" % i, self.cfg.heads
+        Tp = (T + 3) // 4 * 4
+        if self.inject_masks is not None:
+            m = torch.zeros(B * H, T, Tp, device=self.device, dtype=torch.uint8)
+            m[:, :, :T] = self.inject_masks[site].to(self.device, torch.uint8).reshape(B * H, T, T)
+            self.masks[site] = m
+            return m
+        m = self.masks.get(site)
+        if m is None or m.shape != (B * H, T, Tp):
+            m = self.masks[site] = torch.empty(B * H, T, Tp, device=self.device, dtype=torch.uint8)
+        sid = (self.drop_step << 12) + (zlib.crc32(site.encode()) & 0xfff)
+        ops.dropout_mask(m, self._p("attention_dropout"), seed=self.drop_seed, stream_id=sid)
+        return m
+
     def forward_train(self, wav):
         """wav f32 [B,L] -> features f32 [B,T,dim]; keeps the tape for backward()."""
         cfg, w = self.cfg, self.w
@@ -619,9 +637,7 @@ class XlsrFineTuner(XlsrFrontend):
         ws = self._train_ws(B, L)
         tr = ws["tr"]
         T, M, D, Fd = ws["T"], ws["M"], cfg.dim, cfg.ffn
-        if self.train_cfg.attention_dropout > 0 and self.dropout_active:
-            raise OccError("attention_dropout > 0 is not implemented (the published XLS-R configurations use 0)")
-        p_res, p_act, p_ld = self._p("dropout"), self._p("activation_dropout"), self._p("encoder_layerdrop")
+        p_res, p_act, p_ld, p_att = self._p("dropout"), self._p("activation_dropout"), self._p("encoder_layerdrop"), self._p("attention_dropout")
         self.drop_step += 1
         if self.inject_keep is not None:
             self.keep = [bool(k) for k in self.inject_keep]
@@ -651,7 +667,10 @@ class XlsrFineTuner(XlsrFrontend):
                 continue
             ops.layernorm(x_in, w["l%d.ln1.g" % i], w["l%d.ln1.b" % i], out=s["h1"])
             self._lin(i, "qkv.w", s["h1"], "h1", M, 3 * D, D, s["qkv"], rowmap(M, 0, 3 * D), code, bias=w["l%d.qkv.b" % i])
-            ops.attention(s["qkv"], B, T, cfg.heads, hd, hd ** -0.5, out=s["att"], lse=s["lse"])
+            if p_att > 0:                                        # MultiheadAttention: dropout on the attention probabilities (kept for backward)
+                ops.attention_dropout(s["qkv"], B, T, cfg.heads, hd, hd ** -0.5, self._att_keep(i, B, T), p_att, out=s["att"], lse=s["lse"])
+            else:
+                ops.attention(s["qkv"], B, T, cfg.heads, hd, hd ** -0.5, out=s["att"], lse=s["lse"])
             if p_res > 0:                                        # x = residual + dropout1(self_attn(LN(x)))
                 self._lin(i, "o.w", s["att"], "att", M, D, D, tr["y"], xmap, OCC_F32, bias=w["l%d.o.b" % i])
                 self._drop_fwd("l%d.d1" % i, tr["y"], x_mid, p_res, residual=x_in)
@@ -739,7 +758,7 @@ class XlsrFineTuner(XlsrFrontend):
         xmap, fmap, qmap = rowmap(M, 0, D), rowmap(M, 0, Fd), rowmap(M, 0, 3 * D)
         dx, dxb = tr["dx"], tr["dxb"]
         ops.layernorm_bwd(dfeats.contiguous().view(M, D), tr["x_out"], w["enc_ln.g"], None, dx, self.mg["enc_ln.g"], self.mg["enc_ln.b"], dx_bf16=dxb)
-        p_res, p_act = self._p("dropout"), self._p("activation_dropout")
+        p_res, p_act, p_att = self._p("dropout"), self._p("activation_dropout"), self._p("attention_dropout")
         for i in range(cfg.layers - 1, -1, -1):
             s = tr["layers"][i]
             if not self.keep[i]:                                 # a dropped layer: the gradient passes through, its parameters get none
@@ -762,7 +781,10 @@ class XlsrFineTuner(XlsrFrontend):
             if p_res > 0:
                 dyb = tr["dyb"]; self._drop_bwd("l%d.d1" % i, dxb, dyb, p_res)
             self._dgrad(i, "o.w", dyb, "g_o", M, D, D, tr["da"])
-            ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
+            if p_att > 0:
+                ops.attention_bwd_dropout(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, self.masks["l%d.att" % i], p_att, dqkv=tr["dqkv"])
+            else:
+                ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
             self._wgrad_pair(M, (dyb, s["att"], D, D, "l%d.o.w" % i, "l%d.o.b" % i), (tr["dqkv"], s["h1"], 3 * D, D, "l%d.qkv.w" % i, "l%d.qkv.b" % i))
             self._dgrad(i, "qkv.w", tr["dqkv"], "g_qkv", M, D, 3 * D, tr["dh"])
             ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i], dx_bf16=dxb)
@@ -962,9 +984,11 @@ class XlsrFullFineTuner(XlsrFineTuner):
         dmap = rowmap(T, Tp * D, D)
         check(lib().occ_gelu_bwd_rows(ptr(dx), ptr(cv["u_pos"]), du_in, ctypes_byref(dmap), M, D, stream_ptr()), "occ_gelu_bwd_rows")
         K.fill(self.pos_dw.view(-1), 0.0)
-        for g in range(G):
-            K.gemm_tn(M, cg, Kp * cg, du_in + g * cg * 2, dmap, xpad.data_ptr() + g * cg * 2, dmap, self.pos_dw[g], Kp * cg, b_seg=(Kp, cg, D),
-                      colsum_out=self.mg["pos.b"][g * cg:(g + 1) * cg], a_bf16=True, b_bf16=True, bf16_mfma=True)   # operands are bf16 already: same products
+        # all 16 channel groups in ONE launch (grouped occ_gemm_tn: group g reads column slice g of du and of the padded input, writes
+        # pos_dw[g]); the bias gradient is one column sum over the whole du
+        K.gemm_tn(M, cg, Kp * cg, du_in, dmap, xpad, dmap, self.pos_dw, Kp * cg, b_seg=(Kp, cg, D), a_bf16=True, b_bf16=True, bf16_mfma=True,
+                  groups=(G, cg, cg, cg * Kp * cg))
+        K.colsum(du_in, dmap, M, D, self.mg["pos.b"], a_dtype=1)
         sc = ops.small_scratch()
         check(lib().occ_weight_norm_bwd(ptr(self.mp["pos.v"]), ptr(self.mp["pos.g"]), ptr(self.pos_norms), ptr(self.pos_dw), ptr(self.mg["pos.v"]),
                                         ptr(self.mg["pos.g"]), D, cg, Kp, G, ptr(sc), sc.numel(), stream_ptr()), "occ_weight_norm_bwd")

@@ -128,6 +128,34 @@ def attention_bwd(qkv, o, dout, lse, B, T, H, hd, scale, dqkv=None):
     return dqkv
 
 
+def attention_dropout(qkv, B, T, H, hd, scale, keep, p, out=None, lse=None):
+    """attention with fairseq's attention_dropout: keep u8 [B*H, T, Tp] (Tp = T rounded up to 4), p the drop probability."""
+    _dev(qkv)
+    D, Tp = H * hd, (T + 3) // 4 * 4
+    assert qkv.shape == (B * T, 3 * D) and qkv.is_contiguous() and qkv.dtype == torch.bfloat16
+    assert keep.dtype == torch.uint8 and keep.numel() == B * H * T * Tp and keep.is_contiguous()
+    if out is None:
+        out = torch.empty(B * T, D, device=qkv.device, dtype=qkv.dtype)
+    check(lib().occ_attention_dropout(ptr(qkv), ptr(out), B, T, H, hd, 3 * D, D, float(scale), ptr(lse), ptr(keep), float(p), stream_ptr()), "occ_attention_dropout")
+    return out
+
+
+def attention_bwd_dropout(qkv, o, dout, lse, B, T, H, hd, scale, keep, p, dqkv=None):
+    D = H * hd
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    acc = torch.empty(B * T, D, device=qkv.device, dtype=torch.float32) if T > 256 else None
+    check(lib().occ_attention_bwd_dropout(ptr(qkv), ptr(o), ptr(dout), ptr(lse), ptr(dqkv), B, T, H, hd, 3 * D, D, float(scale), ptr(acc), ptr(keep), float(p),
+                                          stream_ptr()), "occ_attention_bwd_dropout")
+    return dqkv
+
+
+def dropout_mask(mask, p, seed=0, stream_id=0):
+    """Fills the u8 tensor `mask` with the keep-mask occ_dropout_ex(generate=1) would draw for (numel, p, seed, stream_id)."""
+    check(lib().occ_dropout_mask(ptr(mask), mask.numel(), float(p), int(seed), int(stream_id), stream_ptr()), "occ_dropout_mask")
+    return mask
+
+
 def _p(t):
     if t is None:
         return ctypes.c_void_p(0)

@@ -44,12 +44,23 @@ class FlatGradAllReducer:
     RCCL runs it on its own stream behind the kernels enqueued so far, under the rest of the backward pass.
     ``all_reduce()`` then covers whatever has not been started and waits for everything."""
 
-    def __init__(self, flat_grad, bucket_bytes=64 << 20, group=None):
+    def __init__(self, flat_grad, bucket_bytes=64 << 20, group=None, wire_dtype=None):
+        """wire_dtype=torch.bfloat16: the gradients cross the links as bf16 (half the payload: 0.63 GB instead of 1.26 GB for XLS-R-300M)
+        -- each slice is rounded into a bf16 staging buffer, summed by the collective in bf16 and widened back into the f32 buffer the
+        optimizer reads (f32 master accumulation after the reduce).  Default (None, or OCC_GRAD_WIRE unset): f32 on the wire, the
+        bit-exact sum of the ranks' gradients."""
         self.flat = flat_grad
         self.group = group
         self.bucket = max(1, bucket_bytes // flat_grad.element_size())
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._started, self._works = [], []
+        if wire_dtype is None and os.environ.get("OCC_GRAD_WIRE", "").lower() in ("bf16", "bfloat16"):
+            wire_dtype = torch.bfloat16
+        if wire_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("wire_dtype must be None / float32 / bfloat16")
+        self.wire = wire_dtype if (wire_dtype == torch.bfloat16 and flat_grad.dtype == torch.float32) else None
+        self._stage = None                                    # bf16 mirror of the flat buffer, allocated on first use (world > 1 only)
+        self._pending = []                                    # (lo, hi) slices whose bf16 sums still have to be widened back
 
     @property
     def buckets(self):
@@ -61,9 +72,15 @@ class FlatGradAllReducer:
         return 1.0 / self.world
 
     def _launch(self, lo, hi):
+        if self.wire is not None:
+            if self._stage is None:
+                self._stage = torch.empty(self.flat.numel(), device=self.flat.device, dtype=self.wire)
+            _cast(self.flat[lo:hi], self._stage[lo:hi])       # on the compute stream, behind the kernels that produced the slice
+            self._pending.append((lo, hi))
+        buf = self.flat if self.wire is None else self._stage
         for a in range(lo, hi, self.bucket):
             b = min(a + self.bucket, hi)
-            self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._works.append(dist.all_reduce(buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def reduce_range(self, lo, hi):
         """Gradients in flat[lo:hi] are final: start their all-reduce now (no-op on one rank)."""
@@ -83,11 +100,23 @@ class FlatGradAllReducer:
         if cur < n:
             self._launch(cur, n)
         works, self._works, self._started = self._works, [], []
-        if async_op:
+        if async_op and self.wire is None:
             return works
         for w in works:
             w.wait()
+        pend, self._pending = self._pending, []
+        for lo, hi in pend:                                  # f32 master accumulation: the optimizer reads the widened sums
+            _cast(self._stage[lo:hi], self.flat[lo:hi])
         return []
+
+
+def _cast(src, dst):
+    """dst[:] = src with dtype conversion (f32 <-> bf16): the library's cast kernel on the GPU, a plain copy on CPU tensors (gloo tests)."""
+    if src.is_cuda:
+        from ._lib import check, dtype_code, lib, ptr, stream_ptr
+        check(lib().occ_cast(ptr(src), dtype_code(src), ptr(dst), dtype_code(dst), src.numel(), stream_ptr()), "occ_cast")
+    else:
+        dst.copy_(src)
 
 
 def max_over_ranks(value, device):

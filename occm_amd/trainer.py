@@ -13,7 +13,7 @@ class OcTrainer:
     0.0 / 1.0 (oc_training.py:380-381); the SE-ResNet script uses 0.1 / 0.9 (test_dataloader_v2.py:127)."""
 
     def __init__(self, model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=False, group_size=None, dropout_masks=None, rawboost_algo=0,
-                 rawboost_args=None, seed=0, rank=0, graph_backend=True):
+                 rawboost_args=None, seed=0, rank=0, graph_backend=True, grad_wire_dtype=None):
         """graph_backend: replay the back-end section of a step (zero_grad, forward, losses, backward: ~560 small launches for AASIST) from a
         HIP graph once a batch shape has come twice in a row (fixed-length training); until then, and for every other shape, steps run eagerly.  Needs device-drawn dropout masks
         (``dropout_masks=None``): injected masks run eagerly."""
@@ -41,7 +41,8 @@ class OcTrainer:
         if train_frontend:                     # XLS-R is trained: its bf16 GEMM operands are written by the optimizer kernel itself
             params.append(self.fe.P); self._grads.append(self.fe.G); mirrors.append(getattr(self.fe, "Wb", None))
         self.opt = ops.AdamMulti(params, lr=lr, bf16_copies=mirrors)
-        self.reducers = [FlatGradAllReducer(g) for g in self._grads]
+        # grad_wire_dtype=torch.bfloat16: the XLS-R gradients (1.26 GB f32) cross xGMI as bf16; the small back-end buffer stays f32
+        self.reducers = [FlatGradAllReducer(g, wire_dtype=grad_wire_dtype if i == 1 else None) for i, g in enumerate(self._grads)]
         self.reducer = self.reducers[0]
         self.last = None
         # frozen front-end: features of the NEXT batch can be computed on a side stream while the back-end trains on this one

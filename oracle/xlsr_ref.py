@@ -94,7 +94,7 @@ def _drop(x, masks, site, p):
     return x * masks[site].to(x.dtype).reshape(x.shape) / (1.0 - p)
 
 
-def encoder_layer(x, p, pre, heads, masks=None, site=None, p_res=0.0, p_act=0.0):
+def encoder_layer(x, p, pre, heads, masks=None, site=None, p_res=0.0, p_act=0.0, p_att=0.0):
     """TransformerSentenceEncoderLayer with layer_norm_first=True (pre-LN).  Train mode (masks given): dropout1 on the attention
     branch, dropout2 (activation_dropout) after the activation, dropout3 on the FFN branch -- fairseq wav2vec2.py
     TransformerSentenceEncoderLayer.forward."""
@@ -107,7 +107,8 @@ def encoder_layer(x, p, pre, heads, masks=None, site=None, p_res=0.0, p_act=0.0)
     q = q.view(B, T, heads, hd).transpose(1, 2)
     k = k.view(B, T, heads, hd).transpose(1, 2)
     v = v.view(B, T, heads, hd).transpose(1, 2)
-    a = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v         # [B,H,T,hd]
+    # MultiheadAttention: attn_probs = dropout(softmax(q k^T), p = attention_dropout) -- keep-mask site "l<i>.att" [B,H,T,T]
+    a = _drop(torch.softmax(q @ k.transpose(-1, -2), dim=-1), masks, "%s.att" % site, p_att) @ v         # [B,H,T,hd]
     a = a.transpose(1, 2).reshape(B, T, D)
     y = F.linear(a, p[pre + ".self_attn.out_proj.weight"], p[pre + ".self_attn.out_proj.bias"])
     x = x + _drop(y, masks, "%s.d1" % site, p_res)
@@ -121,8 +122,8 @@ def extract_feat(wav, p, cfg, taps=None, train=None):
 
     train (optional): fairseq's train-mode behaviour, active in the reference because ``aasist.train()`` (oc_training.py:351) also
     puts the never-eval()-ed SSLModel (sslassist.py:20-29) in train mode.  A dict with the probabilities ``dropout``,
-    ``activation_dropout``, ``dropout_input``, ``feature_grad_mult``, the explicit keep-masks ``masks`` {site: u8} (sites "in",
-    "enc", "l<i>.d1", "l<i>.act", "l<i>.d3") and the layerdrop decisions ``keep`` [bool per layer] -- Wav2Vec2Model.forward and
+    ``activation_dropout``, ``attention_dropout``, ``dropout_input``, ``feature_grad_mult``, the explicit keep-masks ``masks`` {site: u8}
+    (sites "in", "enc", "l<i>.d1", "l<i>.act", "l<i>.d3", "l<i>.att" [B,H,T,T]) and the layerdrop decisions ``keep`` [bool per layer] -- Wav2Vec2Model.forward and
     TransformerEncoder.extract_features of fairseq @ a540213."""
     tr = train or {}
     masks, keep = tr.get("masks"), tr.get("keep")
@@ -149,7 +150,8 @@ def extract_feat(wav, p, cfg, taps=None, train=None):
         taps["pos"] = x
     for i in range(cfg.layers):
         if keep is None or keep[i]:
-            x = encoder_layer(x, p, "encoder.layers.%d" % i, cfg.heads, masks, "l%d" % i, tr.get("dropout", 0.0), tr.get("activation_dropout", 0.0))
+            x = encoder_layer(x, p, "encoder.layers.%d" % i, cfg.heads, masks, "l%d" % i, tr.get("dropout", 0.0), tr.get("activation_dropout", 0.0),
+                              tr.get("attention_dropout", 0.0))
         if taps is not None:
             taps["layer%d" % i] = x
     return F.layer_norm(x, (cfg.dim,), p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"])

@@ -243,8 +243,8 @@ def test_backward_reports_layer_gradient_ranges_for_overlapped_allreduce():
 
 def test_finetuner_train_mode_dropouts_layerdrop_and_feature_grad_mult_match_oracle():
     """fairseq's train-mode behaviour of Wav2Vec2Model (active in the reference: aasist.train(), oc_training.py:351, on an SSLModel that
-    is never eval()-ed): dropout_input on the projection, the encoder's input dropout, dropout1/2/3 of every layer, layerdrop and
-    feature_grad_mult.  The keep-masks the HIP path draws (Philox) are read back and drive the oracle; outputs and every gradient must
+    is never eval()-ed): dropout_input on the projection, the encoder's input dropout, dropout1/2/3 of every layer, attention_dropout
+    on the attention probabilities (inside the fused attention kernels, forward and backward), layerdrop and feature_grad_mult.  The keep-masks the HIP path draws (Philox) are read back and drive the oracle; outputs and every gradient must
     then agree as in eval mode."""
     from oracle import xlsr_ref
     from oracle.fill import fill_like
@@ -257,18 +257,21 @@ def test_finetuner_train_mode_dropouts_layerdrop_and_feature_grad_mult_match_ora
     L = 8000
     wav = 0.1 * _r(2, L, seed=5)
     ft = xlsr.XlsrFullFineTuner({k: v.detach() for k, v in p.items()}, cfg)
-    ft.train_cfg = xlsr.XlsrTrainCfg(dropout=0.1, activation_dropout=0.2, dropout_input=0.15, encoder_layerdrop=0.3, feature_grad_mult=0.25)
+    ft.train_cfg = xlsr.XlsrTrainCfg(dropout=0.1, activation_dropout=0.2, attention_dropout=0.12, dropout_input=0.15, encoder_layerdrop=0.3, feature_grad_mult=0.25)
     ft.inject_keep = [True, False, True]                      # the layerdrop draw is the host's (np.random in fairseq): fixed here
     ft.drop_seed = 7
     out = ft.forward_train(wav.cuda())
     T, D, Fd = xlsr_ref.n_frames(L), 256, 512
     masks = {k: v.cpu() for k, v in ft.masks.items()}
-    assert set(masks) == {"in", "enc", "l0.d1", "l0.act", "l0.d3", "l2.d1", "l2.act", "l2.d3"}         # no masks for the dropped layer
+    assert set(masks) == {"in", "enc", "l0.d1", "l0.act", "l0.d3", "l0.att", "l2.d1", "l2.act", "l2.d3", "l2.att"}         # no masks for the dropped layer
+    att = {k: masks.pop(k)[:, :, :T] for k in ("l0.att", "l2.att")}        # [B*H, T, Tp] on the device: the pad columns are not keys
     for site, pr in (("in", 0.15), ("enc", 0.1), ("l0.act", 0.2), ("l2.d3", 0.1)):
         assert abs(1.0 - float(masks[site].float().mean()) - pr) < 0.02, site                         # drop rates
+    assert abs(1.0 - float(att["l2.att"].float().mean()) - 0.12) < 0.02
     shapes = {"in": (2, T, D), "enc": (2, T, D)}
     om = {k: v.view(shapes.get(k, (2, T, Fd if k.endswith("act") else D))) for k, v in masks.items()}
-    train = dict(dropout=0.1, activation_dropout=0.2, dropout_input=0.15, feature_grad_mult=0.25, masks=om, keep=[True, False, True])
+    om.update({k: v.reshape(2, 4, T, T) for k, v in att.items()})
+    train = dict(dropout=0.1, activation_dropout=0.2, attention_dropout=0.12, dropout_input=0.15, feature_grad_mult=0.25, masks=om, keep=[True, False, True])
     ref = xlsr_ref.extract_feat(wav, p, rcfg, train=train)
     err = (out.cpu() - ref.detach()).abs()
     assert float(err.max()) < 8e-2 and float(err.mean()) < 1.2e-2, (float(err.max()), float(err.mean()))
@@ -291,15 +294,45 @@ def test_finetuner_train_mode_dropouts_layerdrop_and_feature_grad_mult_match_ora
             bad.append((k, round(cos, 5), round(rel, 4)))
     assert not bad, bad[:12]
     assert float(grads["encoder.layers.1.fc1.weight"].abs().max()) == 0.0
-    # a second step draws other masks; attention_dropout is refused
-    m0 = ft.masks["enc"].clone()
+    # a second step draws other masks
+    m0, a0 = ft.masks["enc"].clone(), ft.masks["l0.att"].clone()
     ft.inject_keep = None
     ft.forward_train(wav.cuda())
-    assert not torch.equal(m0, ft.masks["enc"])
-    ft.train_cfg.attention_dropout = 0.1
-    from occm_amd._lib import OccError
-    with pytest.raises(OccError):
-        ft.forward_train(wav.cuda())
+    assert not torch.equal(m0, ft.masks["enc"]) and not torch.equal(a0, ft.masks["l0.att"])
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(2, 199, 3, 64), (1, 61, 2, 64), (1, 300, 2, 64), (2, 199, 2, 80), (1, 650, 1, 80)])
+def test_attention_dropout_fwd_bwd_vs_torch(B, T, H, hd):
+    """occ_attention_dropout / occ_attention_bwd_dropout (keep-mask inside the fused kernels; any T, head dims 64 and 80) against a torch
+    f32 reference on the same bf16 inputs and the same mask; the mask is the one occ_dropout_ex draws for the same Philox stream."""
+    from occm_amd import ops
+    D, p, Tp = H * hd, 0.15, (T + 3) // 4 * 4
+    g = torch.Generator().manual_seed(11)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 0.7).bfloat16()
+    dout = torch.randn(B * T, D, generator=g).bfloat16()
+    keep = torch.empty(B * H, T, Tp, device="cuda", dtype=torch.uint8)
+    ops.dropout_mask(keep, p, seed=5, stream_id=77)
+    same = torch.empty(keep.numel(), device="cuda", dtype=torch.uint8)
+    dummy = torch.zeros(keep.numel(), device="cuda", dtype=torch.bfloat16)
+    ops.dropout_ex(dummy, dummy, same, p, seed=5, stream_id=77, generate=True)
+    assert torch.equal(same.view_as(keep), keep) and abs(1 - float(keep.float().mean()) - p) < 0.01
+    lse = torch.empty(B * H, T, device="cuda")
+    scale = hd ** -0.5
+    out = ops.attention_dropout(qkv.cuda(), B, T, H, hd, scale, keep, p, lse=lse)
+    dqkv = ops.attention_bwd_dropout(qkv.cuda(), out, dout.cuda(), lse, B, T, H, hd, scale, keep, p)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = [x[:, i * D:(i + 1) * D].reshape(B, T, H, hd).transpose(1, 2) for i in range(3)]
+    pr = torch.softmax(q @ k.transpose(-1, -2) * scale, -1)
+    m = keep.cpu()[:, :, :T].reshape(B, H, T, T).float()
+    ref = ((pr * m / (1 - p)) @ v).transpose(1, 2).reshape(B * T, D)
+    ref.backward(dout.float())
+    torch.testing.assert_close(out.cpu().float(), ref.detach(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(lse.cpu() * 0.6931471805599453, torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) * scale, -1).reshape(B * H, T), rtol=1e-3, atol=2e-3)
+    gd, gr = dqkv.cpu().float(), x.grad
+    for i, name in enumerate("qkv"):
+        a, b = gd[:, i * D:(i + 1) * D].reshape(-1), gr[:, i * D:(i + 1) * D].reshape(-1)
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > 0.999 and float((a - b).abs().max()) < 0.03 * float(b.abs().max()) + 1e-3, (name, cos, float((a - b).abs().max()), float(b.abs().max()))
 
 
 @pytest.mark.parametrize("O,I,K,G", [(64, 8, 128, 4), (1024, 64, 128, 16), (48, 12, 64, 2)])

@@ -95,3 +95,35 @@ def test_tn_p8_pair_launch_exact(M, shapes):
     for (C, s), (rc, rs) in zip(outs, refs):
         assert torch.equal(C.cpu().double(), rc), float((C.cpu().double() - rc).abs().max())
         assert torch.equal(s.cpu().double(), rs)
+
+
+@pytest.mark.parametrize("B,T,G,cg,Kp", [(3, 70, 4, 64, 8), (2, 199, 16, 64, 128)])
+def test_grouped_conv_weight_gradient_in_one_launch_exact_integers(B, T, G, cg, Kp):
+    """The positional conv's weight gradient (grouped Conv1d, k = Kp, groups = G: fairseq make_conv_pos) as ONE grouped occ_gemm_tn:
+    group g multiplies column slice g of dY [B*T, D] with the Kp shifted windows of column slice g of the zero-padded input
+    [B, T + Kp, D] (K-segments of cg channels, one per tap).  Small-integer operands: every f32 sum is exact, so any misplaced group,
+    tap segment or row is an integer difference.  Checked against the 16 per-group products of round 2 and an f64 einsum."""
+    from occm_amd import backend_ops as K
+    from occm_amd.ops import rowmap
+    D, M, Tp = G * cg, B * T, T + Kp
+    g = torch.Generator().manual_seed(7)
+    dy = torch.randint(-2, 3, (B, Tp, D), generator=g).float()            # stored in the padded layout, interior rows [Kp/2 - 1, Kp/2 - 1 + T)
+    x = torch.randint(-2, 3, (B, Tp, D), generator=g).float()
+    lo = Kp // 2 - 1
+    dyb, xb = dy.bfloat16().cuda(), x.bfloat16().cuda()
+    dmap = rowmap(T, Tp * D, D)
+    dy_in = dyb.data_ptr() + lo * D * 2
+    C = torch.zeros(G, cg, Kp * cg, device="cuda")
+    K.gemm_tn(M, cg, Kp * cg, dy_in, dmap, xb, dmap, C, Kp * cg, b_seg=(Kp, cg, D), a_bf16=True, b_bf16=True, bf16_mfma=True, groups=(G, cg, cg, cg * Kp * cg))
+    # reference: dW[g, co, tap, ci] = sum_{b,t} dy[b, lo + t, g*cg + co] * x[b, t + tap, g*cg + ci]
+    dyi = dy[:, lo:lo + T].reshape(B, T, G, cg).double()
+    win = torch.stack([x[:, tap:tap + T] for tap in range(Kp)], 2).reshape(B, T, Kp, G, cg).double()
+    ref = torch.einsum("btgo,btkgi->goki", dyi, win).reshape(G, cg, Kp * cg)
+    assert torch.equal(C.cpu().double(), ref), float((C.cpu().double() - ref).abs().max())
+    C1 = torch.zeros_like(C)
+    for gi in range(min(G, 3)):                                           # the per-group launches it replaces give the same integers
+        K.gemm_tn(M, cg, Kp * cg, dy_in + gi * cg * 2, dmap, xb.data_ptr() + gi * cg * 2, dmap, C1[gi], Kp * cg, b_seg=(Kp, cg, D), a_bf16=True, b_bf16=True, bf16_mfma=True)
+        assert torch.equal(C1[gi], C[gi])
+    s = torch.zeros(D, device="cuda")
+    K.colsum(dy_in, dmap, M, D, s, a_dtype=1)
+    assert torch.equal(s.cpu().double(), dy[:, lo:lo + T].reshape(M, D).double().sum(0))

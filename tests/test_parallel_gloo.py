@@ -38,6 +38,23 @@ def _worker(rank, world, port, out):
     ok = ok and torch.allclose(over, expect, atol=1e-6) and red2._started == [] and red2._works == []
     red2.all_reduce()                                                   # second step with nothing pre-started: one more full sum
     ok = ok and torch.allclose(over, expect * world, atol=1e-5)
+    # the overlapped and the one-shot exchange add the same ranks' values element by element: bit-identical results
+    one = torch.randn(1000, generator=torch.Generator().manual_seed(100 + rank))
+    parallel.FlatGradAllReducer(one, bucket_bytes=1 << 20).all_reduce()
+    two = torch.randn(1000, generator=torch.Generator().manual_seed(100 + rank))
+    r3 = parallel.FlatGradAllReducer(two, bucket_bytes=400)
+    r3.reduce_range(900, 1000); r3.reduce_range(0, 250); r3.all_reduce()
+    ok = ok and torch.equal(one, two)
+    # bf16 on the wire (half the payload): equals the f32 exchange to bf16 round-off of the summands and of the sum; results land in
+    # the f32 buffer; overlapped slices and the remainder are all widened back exactly once
+    wb = torch.randn(1000, generator=torch.Generator().manual_seed(100 + rank))
+    r4 = parallel.FlatGradAllReducer(wb, bucket_bytes=400, wire_dtype=torch.bfloat16)
+    r4.reduce_range(300, 600)
+    r4.all_reduce()
+    ok = ok and wb.dtype == torch.float32 and r4._pending == [] and bool(((wb - expect).abs() <= 2.0 ** -7 * (expect.abs() + 4.0)).all())
+    ok = ok and not torch.equal(wb, expect)                              # (it really went through bf16)
+    exact = sum(torch.randn(1000, generator=torch.Generator().manual_seed(100 + k)).bfloat16() for k in range(world)).float()
+    ok = ok and torch.equal(wb, exact)                                   # two ranks: bf16(a) + bf16(b) rounded once to bf16
     mx = parallel.max_over_ranks(1.5 + rank, torch.device("cpu"))
     lo, hi = parallel.shard_groups(5, rank, world)
     parallel.barrier()
