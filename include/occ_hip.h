@@ -398,6 +398,17 @@ int occ_weight_norm_bwd(const float* v, const float* g, const float* norms, cons
 /* dx_bf16 (optional): a bf16 copy of dx for the next input-gradient GEMMs.                                             */
 int occ_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16,
                       float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, float* scratch, int64_t scratch_floats, void* stream);
+/* LayerNorm (f32 rows in, bf16 out) that also writes the fp8 operand of the GEMM consuming it: y_f8 (u8 [rows, C]) = e4m3 of the
+ * bf16-rounded output times *f8_scale (saturating), *f8_amax = max(*f8_amax, |y_bf16|) -- delayed per-tensor scaling, see occ_fp8_quantize. */
+int occ_layernorm_fp8(const float* x, void* y_bf16, void* y_f8, const float* f8_scale, float* f8_amax, const float* gamma, const float* beta,
+                      int64_t rows, int64_t C, float eps, void* stream);
+/* occ_layernorm_bwd with the work of two stand-alone passes folded in (transformer layers of the fine-tuned front-end, where this
+ * LayerNorm's input is x = residual + Linear(.)): dbias (optional f32 [C]) += column sums of the OUTPUT dx = the bias gradient of that
+ * Linear; dx_f8 (optional u8 [rows, C]) = e5m2 of the bf16-rounded dx times *f8_scale (saturating), *f8_amax = max(*f8_amax, |dx_bf16|)
+ * -- the operand and the next-step statistics of the fp8 input-gradient GEMM.  rows >= 2048, C <= 1536, scratch >= 768*C floats.    */
+int occ_layernorm_bwd_fused(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16,
+                            float* dgamma, float* dbeta, float* dbias, void* dx_f8, const float* f8_scale, float* f8_amax, int64_t rows,
+                            int64_t C, float eps, float* scratch, int64_t scratch_floats, void* stream);
 /* The keep-mask of occ_dropout_ex(generate = 1) on its own: mask[i] = 1 with probability 1 - p, Philox4x32-10 counter (i / 4, stream_id),
  * key seed -- the same bytes occ_dropout_ex writes for the same (n, p, seed, stream_id).                                          */
 int occ_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);

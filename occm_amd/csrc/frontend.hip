@@ -34,11 +34,18 @@ template <> struct Vec8<unsigned short> {
     }
 };
 
-template <typename TI, typename TO, int NIT>
+// F8: besides y (bf16) the kernel writes an e4m3 copy of the bf16-rounded outputs times *f8_scale (saturating) and records their |max|
+// in *f8_amax -- operand and next-step statistics of the fp8 GEMM that consumes this LayerNorm (delayed per-tensor scaling), which
+// otherwise cost a separate pass over y.
+template <typename TI, typename TO, int NIT, bool F8 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, TO* __restrict__ y, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, long long rows, int C, float eps, int gelu) {
+                                                       const float* __restrict__ beta, long long rows, int C, float eps, int gelu,
+                                                       unsigned char* __restrict__ yq = nullptr, const float* __restrict__ f8_scale = nullptr,
+                                                       float* __restrict__ f8_amax = nullptr) {
+    __shared__ float wmx[F8 ? 4 : 1];
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    float f8max = 0.f;
+    if (row < rows) {
     const int lane = threadIdx.x & 63;
     const TI* xr = x + row * C;
     float v[NIT][8];
@@ -67,6 +74,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
     TO* yr = y + row * C;
+    const float f8sc = F8 ? *f8_scale : 1.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int c = (it * 64 + lane) * 8;
@@ -80,6 +88,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
                 o[e] = gelu ? gelu_erf(t) : t;
             }
             Vec8<TO>::store(yr + c, o);
+            if constexpr (F8) {
+                float qv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float r = bf16_bits_to_f32(f32_to_bf16_bits(o[e]));       // the value the bf16 tensor holds
+                    f8max = fmaxf(f8max, fabsf(r));
+                    qv[e] = fminf(fmaxf(r * f8sc, -448.f), 448.f);
+                }
+                int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[0], qv[1], 0, false), q1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[4], qv[5], 0, false);
+                q0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[2], qv[3], q0, true); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[6], qv[7], q1, true);
+                *reinterpret_cast<uint2*>(yq + row * C + c) = make_uint2((unsigned)q0, (unsigned)q1);
+            }
+        }
+    }
+    }
+    if constexpr (F8) {                             // one guarded atomic per workgroup (non-negative floats order as their bit patterns)
+        f8max = wave_max(f8max);
+        if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = f8max;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+            if (m > __hip_atomic_load(f8_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(reinterpret_cast<unsigned*>(f8_amax), __float_as_uint(m));
         }
     }
 }
@@ -701,6 +731,19 @@ int occ_layernorm(const void* x, int x_dtype, void* y, int y_dtype, const float*
     else if (x_dtype == OCC_BF16 && y_dtype == OCC_F32) rc = launch_layernorm<unsigned short, float>(x, y, gamma, beta, rows, (int)C, eps, gelu, s);
     if (rc != 0) { occ_set_error("occ_layernorm: unsupported dtype pair %d -> %d", x_dtype, y_dtype); return OCC_EUNSUPPORTED; }
     OCC_LAUNCH_CHECK("occ_layernorm");
+    return OCC_OK;
+}
+
+int occ_layernorm_fp8(const float* x, void* y_bf16, void* y_f8, const float* f8_scale, float* f8_amax, const float* gamma, const float* beta, int64_t rows,
+                      int64_t C, float eps, void* stream) {
+    OCC_CHECK_ARG(x && y_bf16 && y_f8 && f8_scale && f8_amax && gamma && beta, "occ_layernorm_fp8: null pointer");
+    OCC_CHECK_ARG(rows >= 1 && C >= 8 && C % 8 == 0 && C <= 2048, "occ_layernorm_fp8: C must be a multiple of 8 in [8,2048] (C=%ld)", (long)C);
+    const dim3 grid((unsigned)occ_cdiv(rows, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define OCC_LN8(N) hipLaunchKernelGGL((layernorm_kernel<float, unsigned short, N, true>), grid, block, 0, s, x, (unsigned short*)y_bf16, gamma, beta, (long long)rows, (int)C, eps, 0, (unsigned char*)y_f8, f8_scale, f8_amax)
+    switch ((C + 511) / 512) { case 1: OCC_LN8(1); break; case 2: OCC_LN8(2); break; case 3: OCC_LN8(3); break; default: OCC_LN8(4); }
+#undef OCC_LN8
+    OCC_LAUNCH_CHECK("occ_layernorm_fp8");
     return OCC_OK;
 }
 

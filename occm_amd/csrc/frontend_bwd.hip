@@ -252,26 +252,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
 // it, but more WORKGROUPS would multiply the dgamma / dbeta atomics on the same 2C addresses.  Here the per-column sums live in LDS
 // (ds_add_f32 from all 16 waves, lane-contiguous layout: no bank conflicts) instead of 32 registers per lane, which is what lets
 // the wave fit 128 registers; the workgroup still issues one set of global atomics at the end.
-template <typename TDY, typename TX, int NIT, bool GELU>
-__global__ __launch_bounds__(1024) void layernorm_bwd16_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma,
+// WAVES: 16 (128 registers per lane) or 12 (168: room for the EXTRA state without spilling).  EXTRA: (1) the column sums of the
+// OUTPUT dx as a third partial set -- the bias gradient of the Linear whose output gradient this is (out-proj / fc2 of a transformer
+// layer: x = residual + Linear(.)), which was a separate pass over the bf16 copy; (2) an fp8 (e5m2) copy of the bf16-rounded dx
+// with the site's delayed scale, recording |max| for the next step's scale (the fp8 input-gradient GEMM's operand, else its own pass).
+struct LnbExtra { unsigned char* f8; const float* f8_scale; float* f8_amax; int want_bias; };
+template <typename TDY, typename TX, int NIT, bool GELU, int WAVES = 16, bool EXTRA = false>
+__global__ __launch_bounds__(64 * WAVES) void layernorm_bwd16_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ dres, float* __restrict__ dx,
                                                               unsigned short* __restrict__ dx_bf16, RowMapI bmap, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, long long rows, int C, float eps, float* __restrict__ partials) {
+                                                              float* __restrict__ dbeta, long long rows, int C, float eps, float* __restrict__ partials,
+                                                              const LnbExtra ex) {
+    constexpr int NT = 64 * WAVES;
     __shared__ float accg[8 * NIT * 64], accb[8 * NIT * 64];     // [element e of the lane's 8][it*64 + lane]
+    __shared__ float accs[EXTRA ? 8 * NIT * 64 : 4];
+    __shared__ float amx[EXTRA ? WAVES : 1];
     __shared__ __attribute__((aligned(16))) float gs[NIT * 512], bs[GELU ? NIT * 512 : 4];   // gamma / beta: read from LDS at each use (register budget)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 8 * NIT * 64; i += 1024) {
+    for (int i = threadIdx.x; i < 8 * NIT * 64; i += NT) {
         accg[i] = 0.f; accb[i] = 0.f;
+        if (EXTRA) accs[i] = 0.f;
         gs[i] = i < C ? gamma[i] : 0.f;
         if (GELU) bs[i] = i < C ? beta[i] : 0.f;
     }
     __syncthreads();
-    const long long wave0 = (long long)blockIdx.x * 16 + wave, nwaves = (long long)gridDim.x * 16;
+    const long long wave0 = (long long)blockIdx.x * WAVES + wave, nwaves = (long long)gridDim.x * WAVES;
     float dg[NIT][8], db[NIT][8];                  // per-lane column sums over this wave's rows (LDS float atomics per row measured 2.5x slower)
+    float dsum[EXTRA ? NIT : 1][8];
+    float f8max = 0.f;
+    const float f8sc = EXTRA && ex.f8 && ex.f8_scale ? *ex.f8_scale : 1.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; if (EXTRA) dsum[it][e] = 0.f; }
     // no next-row prefetch here: with four waves per SIMD the other waves cover the load latency, and the 24 registers decide whether
     // the kernel fits the 128-register budget of a 16-wave workgroup
     for (long long row = wave0; row < rows; row += nwaves) {
@@ -326,31 +339,64 @@ __global__ __launch_bounds__(1024) void layernorm_bwd16_kernel(const TDY* __rest
                     *reinterpret_cast<float4*>(dx + row * C + c) = make_float4(v[0], v[1], v[2], v[3]);
                     *reinterpret_cast<float4*>(dx + row * C + c + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 }
+                if (EXTRA && ex.want_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dsum[it][e] += v[e];
+                }
                 if (dx_bf16) {
                     unsigned w[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
                     *reinterpret_cast<uint4*>(dx_bf16 + row_off(bmap, row) + c) = make_uint4(w[0], w[1], w[2], w[3]);
+                    if (EXTRA && ex.f8) {           // e5m2 of the bf16-rounded values (what the stand-alone quantisation pass reads), saturating
+                        float qv[8];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float a = __uint_as_float(w[i] << 16), b = __uint_as_float(w[i] & 0xffff0000u);
+                            f8max = fmaxf(f8max, fmaxf(fabsf(a), fabsf(b)));
+                            qv[2 * i] = fminf(fmaxf(a * f8sc, -57344.f), 57344.f); qv[2 * i + 1] = fminf(fmaxf(b * f8sc, -57344.f), 57344.f);
+                        }
+                        int q0 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[0], qv[1], 0, false), q1 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[4], qv[5], 0, false);
+                        q0 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[2], qv[3], q0, true); q1 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[6], qv[7], q1, true);
+                        *reinterpret_cast<uint2*>(ex.f8 + row * C + c) = make_uint2((unsigned)q0, (unsigned)q1);
+                    }
                 }
             }
         }
     }
-    // the sixteen waves add their sums into the LDS arrays one after the other (fixed order), then one set of global atomics
-    for (int w = 0; w < 16; ++w) {
+    // the waves add their sums into the LDS arrays one after the other (fixed order), then one set of global atomics / partial stores
+    for (int w = 0; w < WAVES; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { accg[e * (NIT * 64) + it * 64 + lane] += dg[it][e]; accb[e * (NIT * 64) + it * 64 + lane] += db[it][e]; }
+                for (int e = 0; e < 8; ++e) {
+                    accg[e * (NIT * 64) + it * 64 + lane] += dg[it][e]; accb[e * (NIT * 64) + it * 64 + lane] += db[it][e];
+                    if (EXTRA) accs[e * (NIT * 64) + it * 64 + lane] += dsum[it][e];
+                }
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < 8 * NIT * 64; i += 1024) {
+    if (EXTRA && ex.f8 && ex.f8_amax) {            // one guarded atomic per workgroup (non-negative floats order as their bit patterns)
+        f8max = wave_max(f8max);
+        if (lane == 0) amx[wave] = f8max;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = amx[0];
+            for (int w = 1; w < WAVES; ++w) m = fmaxf(m, amx[w]);
+            if (m > __hip_atomic_load(ex.f8_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(reinterpret_cast<unsigned*>(ex.f8_amax), __float_as_uint(m));
+        }
+    }
+    constexpr int NS = EXTRA ? 3 : 2;              // partial sets per block: dgamma, dbeta (, bias)
+    for (int i = threadIdx.x; i < 8 * NIT * 64; i += NT) {
         const int e = i / (NIT * 64), l = i - e * (NIT * 64), c = l * 8 + e;
         if (c < C) {
             // 256 workgroups adding to the same 2C addresses cost ~25 us of a 77 us launch: with caller scratch the sums go out as
-            // plain stores [block][2][C] and layernorm_bwd_finalize_kernel adds them up in block order
-            if (partials) { partials[((long long)blockIdx.x * 2) * C + c] = accg[i]; partials[((long long)blockIdx.x * 2 + 1) * C + c] = accb[i]; }
+            // plain stores [block][sets][C] and layernorm_bwd_finalize_kernel adds them up in block order
+            if (partials) {
+                partials[((long long)blockIdx.x * NS) * C + c] = accg[i]; partials[((long long)blockIdx.x * NS + 1) * C + c] = accb[i];
+                if (EXTRA) partials[((long long)blockIdx.x * NS + 2) * C + c] = accs[i];
+            }
             else { atomicAdd(dgamma + c, accg[i]); atomicAdd(dbeta + c, accb[i]); }
         }
     }
@@ -358,27 +404,28 @@ __global__ __launch_bounds__(1024) void layernorm_bwd16_kernel(const TDY* __rest
 
 // 64 columns per workgroup; the four waves take every fourth block (independent loads, eight in flight), wave 0 adds the four sums
 __global__ __launch_bounds__(256) void layernorm_bwd_finalize_kernel(const float* __restrict__ partials, int nblocks, int C, float* __restrict__ dgamma,
-                                                                    float* __restrict__ dbeta) {
+                                                                    float* __restrict__ dbeta, float* __restrict__ dbias, int nsets) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;                  // [2][C]
+    const int i = blockIdx.x * 64 + lane;                  // [nsets][C]
+    const int tot = nsets * C;
     float s = 0.f;
-    if (i < 2 * C) {
+    if (i < tot) {
         int b = wave;
         for (; b + 28 < nblocks; b += 32) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partials[(long long)(b + 4 * u) * 2 * C + i];
+            for (int u = 0; u < 8; ++u) v[u] = partials[(long long)(b + 4 * u) * tot + i];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; b < nblocks; b += 4) s += partials[(long long)b * 2 * C + i];
+        for (; b < nblocks; b += 4) s += partials[(long long)b * tot + i];
     }
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && i < 2 * C) {
+    if (wave == 0 && i < tot) {
         const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-        if (i < C) dgamma[i] += t; else dbeta[i - C] += t;
+        if (i < C) dgamma[i] += t; else if (i < 2 * C) dbeta[i - C] += t; else if (dbias) dbias[i - 2 * C] += t;
     }
 }
 
@@ -745,9 +792,31 @@ int occ_transpose_bf16(const void* src, int src_dtype, void* dst, int64_t rows, 
     return occ_transpose_bf16_rows(src, src_dtype, &m, dst, rows, cols, ld_dst, colsum, stream);
 }
 
+static int lnb_impl(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta, const float* dres, float* dx,
+                    void* dx_bf16, const occ_rowmap* dx_bf16_map, float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, int gelu,
+                    float* scratch, int64_t scratch_floats, void* stream, float* dbias, void* dx_f8, const float* f8_scale, float* f8_amax);
+
 int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta, const float* dres, float* dx,
                          void* dx_bf16, const occ_rowmap* dx_bf16_map, float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, int gelu,
                          float* scratch, int64_t scratch_floats, void* stream) {
+    return lnb_impl(dy, dy_dtype, x, x_dtype, gamma, beta, dres, dx, dx_bf16, dx_bf16_map, dgamma, dbeta, rows, C, eps, gelu, scratch, scratch_floats, stream,
+                    nullptr, nullptr, nullptr, nullptr);
+}
+
+int occ_layernorm_bwd_fused(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
+                            float* dbeta, float* dbias, void* dx_f8, const float* f8_scale, float* f8_amax, int64_t rows, int64_t C, float eps,
+                            float* scratch, int64_t scratch_floats, void* stream) {
+    OCC_CHECK_ARG(dbias || dx_f8, "occ_layernorm_bwd_fused: nothing to fuse (use occ_layernorm_bwd)");
+    OCC_CHECK_ARG(!dx_f8 || (dx_bf16 && f8_scale), "occ_layernorm_bwd_fused: the fp8 copy is made of the bf16 output and needs its scale");
+    OCC_CHECK_ARG(rows >= 2048 && C <= 1536 && scratch && scratch_floats >= 256 * 3 * C && ((uintptr_t)scratch & 15) == 0,
+                  "occ_layernorm_bwd_fused: needs rows >= 2048, C <= 1536 and 768*C floats of 16-byte aligned scratch");
+    return lnb_impl(dy, dy_dtype, x, OCC_F32, gamma, nullptr, dres, dx, dx_bf16, nullptr, dgamma, dbeta, rows, C, eps, 0, scratch, scratch_floats, stream,
+                    dbias, dx_f8, f8_scale, f8_amax);
+}
+
+static int lnb_impl(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta, const float* dres, float* dx,
+                    void* dx_bf16, const occ_rowmap* dx_bf16_map, float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, int gelu,
+                    float* scratch, int64_t scratch_floats, void* stream, float* dbias, void* dx_f8, const float* f8_scale, float* f8_amax) {
     OCC_CHECK_ARG(dy && x && gamma && (dx || dx_bf16) && dgamma && dbeta, "occ_layernorm_bwd: null pointer");
     OCC_CHECK_ARG(!gelu || beta, "occ_layernorm_bwd: the fused GELU needs beta");
     OCC_CHECK_ARG(rows >= 1 && C >= 8 && C % 8 == 0 && C <= 2048, "occ_layernorm_bwd: C must be a multiple of 8 in [8,2048]");
@@ -762,7 +831,21 @@ int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
     RowMapI bm = occ_make_rowmap(rows, 0, C, 0, 0);
     if (dx_bf16_map) { OCC_CHECK_ARG(dx_bf16_map->rows_per_batch >= 1 && dx_bf16_map->row_stride % 8 == 0 && dx_bf16_map->batch_stride % 8 == 0, "occ_layernorm_bwd: bad bf16 row map"); bm = to_rowmap(*dx_bf16_map); }
 #define OCC_LNB(TD, TXX, N, G) hipLaunchKernelGGL((layernorm_bwd_kernel<TD, TXX, N, G>), dim3((unsigned)blocks), dim3(256), 0, s, (const TD*)dy, (const TXX*)x, gamma, beta, dres, dx, (unsigned short*)dx_bf16, bm, dgamma, dbeta, (long long)rows, (int)C, eps)
-#define OCC_LNB16(TD, TXX, N, G) hipLaunchKernelGGL((layernorm_bwd16_kernel<TD, TXX, N, G>), dim3((unsigned)blocks16), dim3(1024), 0, s, (const TD*)dy, (const TXX*)x, gamma, beta, dres, dx, (unsigned short*)dx_bf16, bm, dgamma, dbeta, (long long)rows, (int)C, eps, part)
+#define OCC_LNB16(TD, TXX, N, G) hipLaunchKernelGGL((layernorm_bwd16_kernel<TD, TXX, N, G>), dim3((unsigned)blocks16), dim3(1024), 0, s, (const TD*)dy, (const TXX*)x, gamma, beta, dres, dx, (unsigned short*)dx_bf16, bm, dgamma, dbeta, (long long)rows, (int)C, eps, part, LnbExtra{nullptr, nullptr, nullptr, 0})
+    if (dbias || dx_f8) {                           // the fused form (transformer layers): 12 waves per workgroup, three partial sets
+        const int nitx = (int)((C + 511) / 512);
+        long long bl = occ_cdiv(rows, 12 * 4);
+        if (bl > 256) bl = 256;
+        const LnbExtra ex{(unsigned char*)dx_f8, f8_scale, f8_amax, dbias ? 1 : 0};
+        // C <= 1024: 12 waves (158 registers, no spill); 1024 < C <= 1536 (XLS-R-1B: 1280): 8 waves, whose 256-register budget holds the 120 accumulators
+#define OCC_LNBX(TD, N, W) hipLaunchKernelGGL((layernorm_bwd16_kernel<TD, float, N, false, W, true>), dim3((unsigned)bl), dim3(64 * W), 0, s, (const TD*)dy, (const float*)x, gamma, beta, dres, dx, (unsigned short*)dx_bf16, bm, dgamma, dbeta, (long long)rows, (int)C, eps, scratch, ex)
+        if (dy_dtype == OCC_F32) { if (nitx == 1) OCC_LNBX(float, 1, 12); else if (nitx == 2) OCC_LNBX(float, 2, 12); else OCC_LNBX(float, 3, 8); }
+        else { if (nitx == 1) OCC_LNBX(unsigned short, 1, 12); else if (nitx == 2) OCC_LNBX(unsigned short, 2, 12); else OCC_LNBX(unsigned short, 3, 8); }
+#undef OCC_LNBX
+        hipLaunchKernelGGL(layernorm_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(3 * C, 64)), dim3(256), 0, s, scratch, (int)bl, (int)C, dgamma, dbeta, dbias, 3);
+        OCC_LAUNCH_CHECK("occ_layernorm_bwd_fused");
+        return OCC_OK;
+    }
     static const int lnb16 = getenv("OCC_LNB16") ? atoi(getenv("OCC_LNB16")) : 1;
     long long blocks16 = occ_cdiv(rows, 16 * 4);        // >= 4 rows per wave
     if (blocks16 > lnb_blocks) blocks16 = lnb_blocks;
@@ -781,7 +864,7 @@ int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
 #undef OCC_LNB_N
 #undef OCC_LNB16
 #undef OCC_LNB
-    if (part) hipLaunchKernelGGL(layernorm_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(2 * C, 64)), dim3(256), 0, s, part, (int)blocks16, (int)C, dgamma, dbeta);
+    if (part) hipLaunchKernelGGL(layernorm_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(2 * C, 64)), dim3(256), 0, s, part, (int)blocks16, (int)C, dgamma, dbeta, (float*)nullptr, 2);
     OCC_LAUNCH_CHECK("occ_layernorm_bwd");
     return OCC_OK;
 }

@@ -400,6 +400,7 @@ class XlsrFineTuner(XlsrFrontend):
         self.drop_seed, self.drop_step = 0, 0
         self.inject_masks, self.inject_keep = None, None
         self.masks, self.keep = {}, None
+        self._f8_pre = None                                      # (kind, site) of an fp8 operand a producing kernel has already written
         self.seed_layerdrop(0)
 
     def seed_layerdrop(self, seed):
@@ -572,7 +573,12 @@ class XlsrFineTuner(XlsrFrontend):
         if not getattr(self, "fp8", False):
             ops.gemm_raw(M, N, K, a, rowmap(M, 0, K), self.w[name], K, C, c_map, c_dtype, OCC_BF16_CODE, **kw)
             return
-        q, inv_a = self._fp8_q(a, 4, i * 8 + self._E4[site])
+        k4 = i * 8 + self._E4[site]
+        if self._f8_pre == (4, k4):                               # the producing kernel (LayerNorm) already wrote the e4m3 operand
+            q, inv_a = self.f8["qa"][: a.numel()], self.f8["inv4"][k4:k4 + 1]
+        else:
+            q, inv_a = self._fp8_q(a, 4, k4)
+        self._f8_pre = None
         kw_ = i * 8 + self._E4[wn]
         ops.gemm_raw(M, N, K, q, rowmap(M, 0, K), self.f8["wq"][name], K, C, c_map, c_dtype, self.f8["e4"], a_dequant=inv_a, w_dequant=self.f8["inv4"][kw_:kw_ + 1], **kw)
 
@@ -582,10 +588,50 @@ class XlsrFineTuner(XlsrFrontend):
         if not getattr(self, "fp8", False):
             ops.gemm_raw(M, N, K, dy, rowmap(M, 0, K), self.wT[name], K, C, rowmap(M, 0, N), OCC_BF16_CODE, OCC_BF16_CODE, **kw)
             return
-        q, inv_g = self._fp8_q(dy, 5, i * 4 + self._E5[gsite])
+        k5 = i * 4 + self._E5[gsite]
+        if self._f8_pre == (5, k5):                               # the producing kernel (LayerNorm backward) already wrote the e5m2 operand
+            q, inv_g = self.f8["qg"][: dy.numel()], self.f8["inv5"][k5:k5 + 1]
+        else:
+            q, inv_g = self._fp8_q(dy, 5, k5)
+        self._f8_pre = None
         kw_ = i * 8 + self._E4[wn]
         ops.gemm_raw(M, N, K, q, rowmap(M, 0, K), self.f8["wtq"][name], K, C, rowmap(M, 0, N), OCC_BF16_CODE, self.f8["e5"], a_dequant=inv_g,
                      w_dequant=self.f8["inv4"][kw_:kw_ + 1], **kw)
+
+    def _f8_buf(self, kind, numel):
+        key = "qa" if kind == 4 else "qg"
+        if self.f8[key] is None or self.f8[key].numel() < numel:
+            self.f8[key] = torch.empty(numel, device=self.device, dtype=torch.uint8)
+        return self.f8[key][:numel]
+
+    def _ln_fwd(self, i, x, ln, out, site):
+        """LayerNorm `ln` ("ln1" / "ln2") of layer i into the bf16 operand `out`; on the fp8 path (delayed scales known) the same kernel also
+        writes the e4m3 operand of the GEMM that follows (site "h1" / "h2"): no stand-alone quantisation pass."""
+        g, b = self.w["l%d.%s.g" % (i, ln)], self.w["l%d.%s.b" % (i, ln)]
+        if getattr(self, "fp8", False) and not self.f8["warm"]:
+            k4 = i * 8 + self._E4[site]
+            ops.layernorm_fp8(x, g, b, out, self._f8_buf(4, out.numel()), self.f8["scale4"][k4:k4 + 1], self.f8["amax4"][k4:k4 + 1])
+            self._f8_pre = (4, k4)
+        else:
+            ops.layernorm(x, g, b, out=out)
+
+    def _ln_bwd(self, dy, x, gname, dres, dx, dxb, bias_name=None, f8_site=None):
+        """LayerNorm backward into dx (f32) + dxb (bf16).  Where the gradient it produces is the output gradient of a Linear (x = residual +
+        Linear(.): out-proj / fc2), the same kernel also sums its columns into that Linear's bias gradient (bias_name) and, on the fp8 path,
+        writes the e5m2 operand of that Linear's input-gradient GEMM (f8_site = index into the gradient-site scales).  Returns True when the
+        bias gradient was taken care of."""
+        M, C = dx.shape
+        f8 = getattr(self, "fp8", False) and f8_site is not None and not self.f8["warm"]
+        if (bias_name is not None or f8) and M >= 2048 and C <= 1536:
+            q = self._f8_buf(5, M * C) if f8 else None
+            ops.layernorm_bwd_fused(dy, x, self.w[gname + ".g"], dres, dx, self.mg[gname + ".g"], self.mg[gname + ".b"], dxb,
+                                    dbias=self.mg[bias_name] if bias_name is not None else None, dx_f8=q,
+                                    f8_scale=self.f8["scale5"][f8_site:f8_site + 1] if f8 else None, f8_amax=self.f8["amax5"][f8_site:f8_site + 1] if f8 else None)
+            if f8:
+                self._f8_pre = (5, f8_site)
+            return bias_name is not None
+        ops.layernorm_bwd(dy, x, self.w[gname + ".g"], dres, dx, self.mg[gname + ".g"], self.mg[gname + ".b"], dx_bf16=dxb)
+        return False
 
     # ---- train-mode dropouts ---------------------------------------------------------------------------------------------
     def _p(self, field):
@@ -665,7 +711,7 @@ class XlsrFineTuner(XlsrFrontend):
             if not self.keep[i]:                                 # layerdrop: the layer is skipped, the residual stream passes through
                 x_next.copy_(x_in)
                 continue
-            ops.layernorm(x_in, w["l%d.ln1.g" % i], w["l%d.ln1.b" % i], out=s["h1"])
+            self._ln_fwd(i, x_in, "ln1", s["h1"], "h1")
             self._lin(i, "qkv.w", s["h1"], "h1", M, 3 * D, D, s["qkv"], rowmap(M, 0, 3 * D), code, bias=w["l%d.qkv.b" % i])
             if p_att > 0:                                        # MultiheadAttention: dropout on the attention probabilities (kept for backward)
                 ops.attention_dropout(s["qkv"], B, T, cfg.heads, hd, hd ** -0.5, self._att_keep(i, B, T), p_att, out=s["att"], lse=s["lse"])
@@ -676,7 +722,7 @@ class XlsrFineTuner(XlsrFrontend):
                 self._drop_fwd("l%d.d1" % i, tr["y"], x_mid, p_res, residual=x_in)
             else:
                 self._lin(i, "o.w", s["att"], "att", M, D, D, x_mid, xmap, OCC_F32, bias=w["l%d.o.b" % i], R=x_in, r_map=xmap, r_dtype=OCC_F32)
-            ops.layernorm(x_mid, w["l%d.ln2.g" % i], w["l%d.ln2.b" % i], out=s["h2"])
+            self._ln_fwd(i, x_mid, "ln2", s["h2"], "h2")
             self._lin(i, "fc1.w", s["h2"], "h2", M, Fd, D, s["f"], rowmap(M, 0, Fd), code, bias=w["l%d.fc1.b" % i], act=ACT_GELU, aux=s["u"])
             if p_act > 0:                                        # dropout2 on the activation
                 self._drop_fwd("l%d.act" % i, s["f"], s["f"], p_act)
@@ -735,7 +781,7 @@ class XlsrFineTuner(XlsrFrontend):
     def _wgrad_pair(self, M, a, b):
         """Two weight (+ bias) gradients of one layer, (dy, x, N, Kd, gname, bias_name) each, in one launch (occ_gemm_tn_pair)."""
         from .. import backend_ops as K
-        K.gemm_tn_pair(M, *[(N, Kd, dy, rowmap(M, 0, N), x, rowmap(M, 0, Kd), self.mg[g], Kd, self.mg[bn]) for dy, x, N, Kd, g, bn in (a, b)])
+        K.gemm_tn_pair(M, *[(N, Kd, dy, rowmap(M, 0, N), x, rowmap(M, 0, Kd), self.mg[g], Kd, self.mg[bn] if bn is not None else None) for dy, x, N, Kd, g, bn in (a, b)])
 
     def layer_grad_range(self, i):
         """[lo, hi) of transformer layer i's gradients in the flat buffer self.G (its twelve tensors are contiguous)."""
@@ -757,8 +803,19 @@ class XlsrFineTuner(XlsrFrontend):
         bfc, hd = OCC_BF16_CODE, D // cfg.heads
         xmap, fmap, qmap = rowmap(M, 0, D), rowmap(M, 0, Fd), rowmap(M, 0, 3 * D)
         dx, dxb = tr["dx"], tr["dxb"]
-        ops.layernorm_bwd(dfeats.contiguous().view(M, D), tr["x_out"], w["enc_ln.g"], None, dx, self.mg["enc_ln.g"], self.mg["enc_ln.b"], dx_bf16=dxb)
         p_res, p_act, p_att = self._p("dropout"), self._p("activation_dropout"), self._p("attention_dropout")
+        # A LayerNorm backward's output is the output gradient of the Linear below it in the residual chain (the final LayerNorm and every
+        # ln1: fc2 of the next kept layer down; ln2: this layer's out-proj): with no residual dropout in between that kernel also produces the
+        # Linear's bias gradient and, on the fp8 path, its e5m2 GEMM operand.
+        fuse = p_res == 0
+        kept = [i for i in range(cfg.layers) if self.keep[i]]
+        below = lambda i: max([j for j in kept if j < i], default=None)      # the kept layer whose output gradient ln1-backward of layer i produces
+        top = kept[-1] if kept else None
+        fc2_bias_done = {}
+        done = self._ln_bwd(dfeats.contiguous().view(M, D), tr["x_out"], "enc_ln", None, dx, dxb, bias_name="l%d.fc2.b" % top if fuse and top is not None else None,
+                            f8_site=top * 4 + self._E5["g_fc2"] if fuse and top is not None else None)
+        if top is not None:
+            fc2_bias_done[top] = done
         for i in range(cfg.layers - 1, -1, -1):
             s = tr["layers"][i]
             if not self.keep[i]:                                 # a dropped layer: the gradient passes through, its parameters get none
@@ -773,9 +830,11 @@ class XlsrFineTuner(XlsrFrontend):
             if p_act > 0:                                        # (elementwise factors commute: mask after GELU')
                 self._drop_bwd("l%d.act" % i, tr["du"], tr["du"], p_act)
             # both FFN weight gradients in one launch (dyb is not rewritten before the LayerNorm backward below)
-            self._wgrad_pair(M, (dyb, s["f"], D, Fd, "l%d.fc2.w" % i, "l%d.fc2.b" % i), (tr["du"], s["h2"], Fd, D, "l%d.fc1.w" % i, "l%d.fc1.b" % i))
+            self._wgrad_pair(M, (dyb, s["f"], D, Fd, "l%d.fc2.w" % i, None if fc2_bias_done.get(i) else "l%d.fc2.b" % i),
+                             (tr["du"], s["h2"], Fd, D, "l%d.fc1.w" % i, "l%d.fc1.b" % i))
             self._dgrad(i, "fc1.w", tr["du"], "g_fc1", M, D, Fd, tr["dh"])
-            ops.layernorm_bwd(tr["dh"], s["x_mid"], w["l%d.ln2.g" % i], dx, dx, self.mg["l%d.ln2.g" % i], self.mg["l%d.ln2.b" % i], dx_bf16=dxb)
+            o_bias_done = self._ln_bwd(tr["dh"], s["x_mid"], "l%d.ln2" % i, dx, dx, dxb, bias_name="l%d.o.b" % i if fuse else None,
+                                       f8_site=i * 4 + self._E5["g_o"] if fuse else None)
             # ---- attention: x_mid = x_in + dropout1(out_proj(attn(qkv(LN1(x_in)))))
             dyb = dxb
             if p_res > 0:
@@ -785,9 +844,14 @@ class XlsrFineTuner(XlsrFrontend):
                 ops.attention_bwd_dropout(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, self.masks["l%d.att" % i], p_att, dqkv=tr["dqkv"])
             else:
                 ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
-            self._wgrad_pair(M, (dyb, s["att"], D, D, "l%d.o.w" % i, "l%d.o.b" % i), (tr["dqkv"], s["h1"], 3 * D, D, "l%d.qkv.w" % i, "l%d.qkv.b" % i))
+            self._wgrad_pair(M, (dyb, s["att"], D, D, "l%d.o.w" % i, None if o_bias_done else "l%d.o.b" % i),
+                             (tr["dqkv"], s["h1"], 3 * D, D, "l%d.qkv.w" % i, "l%d.qkv.b" % i))
             self._dgrad(i, "qkv.w", tr["dqkv"], "g_qkv", M, D, 3 * D, tr["dh"])
-            ops.layernorm_bwd(tr["dh"], s["x_in"], w["l%d.ln1.g" % i], dx, dx, self.mg["l%d.ln1.g" % i], self.mg["l%d.ln1.b" % i], dx_bf16=dxb)
+            j = below(i)
+            done = self._ln_bwd(tr["dh"], s["x_in"], "l%d.ln1" % i, dx, dx, dxb, bias_name="l%d.fc2.b" % j if fuse and j is not None else None,
+                                f8_site=j * 4 + self._E5["g_fc2"] if fuse and j is not None else None)
+            if j is not None:
+                fc2_bias_done[j] = done
             if grad_ready is not None:
                 grad_ready(*self.layer_grad_range(i))
         if p_res > 0:                                            # the encoder's input dropout

@@ -284,6 +284,24 @@ def layernorm_bwd(dy, x, gamma, dres, dx, dgamma, dbeta, eps=1e-5, dx_bf16=None)
     return dx
 
 
+def layernorm_fp8(x, gamma, beta, out, out_f8, f8_scale, f8_amax, eps=1e-5):
+    """LayerNorm f32 -> bf16 `out` plus the e4m3 copy `out_f8` (u8, same shape) at the delayed scale, recording |max| in f8_amax."""
+    C = x.shape[-1]
+    check(lib().occ_layernorm_fp8(ptr(x), ptr(out), ptr(out_f8), ptr(f8_scale), ptr(f8_amax), ptr(gamma), ptr(beta), x.numel() // C, C, float(eps), stream_ptr()),
+          "occ_layernorm_fp8")
+    return out
+
+
+def layernorm_bwd_fused(dy, x, gamma, dres, dx, dgamma, dbeta, dx_bf16, dbias=None, dx_f8=None, f8_scale=None, f8_amax=None, eps=1e-5):
+    """layernorm_bwd with the bias gradient of the preceding Linear (column sums of dx) and / or the e5m2 copy of the bf16 dx folded in."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    sc = small_scratch()
+    check(lib().occ_layernorm_bwd_fused(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(dgamma), ptr(dbeta), ptr(dbias),
+                                        ptr(dx_f8), ptr(f8_scale), ptr(f8_amax), rows, C, float(eps), ptr(sc), sc.numel(), stream_ptr()), "occ_layernorm_bwd_fused")
+    return dx
+
+
 # ---------------------------------------------------------------------------------- RawBoost ---
 def rawboost_fir_bank(x, coef, ntaps, powers):
     """x f32/f64 [B,L]; coef f64 [B,F,max_taps]; ntaps i32 [B,F] -> y f64 [B,L]."""

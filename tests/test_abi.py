@@ -40,7 +40,11 @@ def test_host_argument_validation_needs_no_gpu():
 _NO_SCRATCH = ["gemm_bf16_dma_kernelILi128ELb0ELi128", "gemm_bf16_dma_kernelILi128ELb1ELi128", "gemm_bf16_dma_kernelILi256", "gemm_bf16_hs_kernel", "gemm_bf16_ks2_kernel", "gemm_bf16_dma_n64_kernel",
                "gemm_kernelILi2ELi64", "gemm_kernelILi2ELi128", "gemm_tn_bf16_kernel", "gemm_tn_dma_kernelILi4", "gemm_tn_dma_kernelILi1", "attention_mfma_head_kernelILi7ELi8", "attention_mfma_head_kernelILi7ELi4",
                "attention_mfma_long_kernelILi64", "attention_mfma_kernelILi4", "conv0_ln_gelu_kernelItLi10", "layernorm_kernelIftLi2", "conv0_bwd_kernel",
-               "fir_bank_kernel", "adam_multi_kernel"]
+               "fir_bank_kernel", "adam_multi_kernel",
+               # round 3: this round's hot kernels (the eight-phase GEMMs in all formats, the weight-gradient kernels, attention backward incl.
+               # its dropout form, the fused LayerNorm backward of the transformer layers and the conv stack's LayerNorm+GELU backward)
+               "gemm_p8_kernel", "gemm_tn_p8_kernel", "gemm_tn_p8_pair_kernel", "attention_bwd2_kernelILi64ELb0", "attention_bwd2_kernelILi80ELb0", "attention_bwd2_kernelILi64ELb1", "layernorm_bwd16_kernelItfLi2ELb0ELi12ELb1",
+               "layernorm_bwd16_kernelItfLi3ELb0ELi8ELb1", "layernorm_bwd16_kernelIttLi1ELb1", "layernorm_kernelIftLi2ELb1", "attention_mfma_long_kernel"]
 
 
 def test_hot_kernels_do_not_spill():

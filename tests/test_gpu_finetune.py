@@ -58,6 +58,46 @@ def test_layernorm_bwd(C):
     torch.testing.assert_close(dx2.cpu(), x.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("C", [1024, 1280, 512])
+def test_layernorm_fused_forms_equal_the_separate_passes(C):
+    """occ_layernorm_bwd_fused (bias column sums of the output + e5m2 copy + |max|) and occ_layernorm_fp8 (e4m3 copy + |max|) against the
+    kernels and stand-alone passes they replace: dx / dx_bf16 / dgamma / dbeta as occ_layernorm_bwd gives them, the bias gradient as the
+    column sum of dx, the fp8 bytes and |max| bit-identical to occ_fp8_quantize of the bf16 tensor at the same scale."""
+    from occm_amd import backend_ops as K
+    from occm_amd import ops
+    from occm_amd._lib import OCC_FP8_E4M3, OCC_FP8_E5M2
+    rows = 2304 + 7
+    x = (_r(rows, C, seed=2) * 2 + 0.3).cuda()
+    g, b = (1 + 0.1 * _r(C, seed=3)).cuda(), (0.1 * _r(C, seed=4)).cuda()
+    dy, dres = _r(rows, C, seed=5).bfloat16().cuda(), _r(rows, C, seed=6).cuda()
+    z = lambda *sh, dt=torch.float32: torch.zeros(*sh, device="cuda", dtype=dt)
+    # ---- backward
+    dx0, dxb0, dg0, db0 = z(rows, C), z(rows, C, dt=torch.bfloat16), z(C), z(C)
+    ops.layernorm_bwd(dy, x, g, dres, dx0, dg0, db0, dx_bf16=dxb0)
+    scale, amax0, amax1 = torch.tensor([37.5], device="cuda"), z(1), z(1)
+    q0 = torch.empty(rows * C, device="cuda", dtype=torch.uint8)
+    ops.fp8_quantize(dxb0, q0, OCC_FP8_E5M2, scale=scale, amax=amax0)
+    dx1, dxb1, dg1, db1, dbias = z(rows, C), z(rows, C, dt=torch.bfloat16), z(C), z(C), torch.full((C,), 0.25, device="cuda")
+    q1 = torch.empty(rows * C, device="cuda", dtype=torch.uint8)
+    ops.layernorm_bwd_fused(dy, x, g, dres, dx1, dg1, db1, dxb1, dbias=dbias, dx_f8=q1, f8_scale=scale, f8_amax=amax1)
+    assert torch.equal(dx1, dx0) and torch.equal(dxb1, dxb0)
+    torch.testing.assert_close(dg1, dg0, rtol=1e-4, atol=1e-3); torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dbias, 0.25 + dx0.double().sum(0).float(), rtol=1e-4, atol=2e-3)          # accumulates onto what the buffer holds
+    assert torch.equal(q1, q0) and float(amax1) == float(amax0) > 0
+    # bias only (the bf16 fine-tuning step) and fp8 only
+    dbias2 = z(C)
+    ops.layernorm_bwd_fused(dy, x, g, dres, dx1, dg1, db1, dxb1, dbias=dbias2)
+    torch.testing.assert_close(dbias2, dx0.double().sum(0).float(), rtol=1e-4, atol=2e-3)
+    # ---- forward
+    h0 = z(rows, C, dt=torch.bfloat16)
+    ops.layernorm(x, g, b, out=h0)
+    sc4, a0, a1 = torch.tensor([90.0], device="cuda"), z(1), z(1)
+    ops.fp8_quantize(h0, q0, OCC_FP8_E4M3, scale=sc4, amax=a0)
+    h1 = z(rows, C, dt=torch.bfloat16)
+    ops.layernorm_fp8(x, g, b, h1, q1, sc4, a1)
+    assert torch.equal(h1, h0) and torch.equal(q1, q0) and float(a1) == float(a0) > 0
+
+
 @pytest.mark.parametrize("B,T,H,hd", [(2, 199, 4, 64), (1, 37, 2, 64), (2, 256, 1, 64), (1, 64, 3, 64), (1, 1, 1, 64), (3, 17, 2, 64),
                                       # longer than one key block (variable-length groups, oc_training.py:244-249): key blocks meet in the f32 dq accumulator
                                       (1, 257, 2, 64), (2, 400, 2, 64), (1, 650, 3, 64), (1, 1030, 1, 64),
