@@ -136,6 +136,11 @@ typedef struct occ_gemm_desc {
     /* fp8 operands (ab_dtype OCC_FP8_*): device scalars 1/scale of the per-tensor quantisation of A and W; the accumulator is
      * multiplied by alpha * (*a_dequant) * (*w_dequant) before bias.  NULL = 1.                                           */
     const float* a_dequant; const float* w_dequant;
+    /* Optional fp8 copy of a bf16 result, written by the same epilogue (delayed per-tensor scaling: the operand of the NEXT fp8 GEMM,
+     * which otherwise costs a quantisation pass over C): c_f8 u8 [M, N] (plain rows) = fp8 of the bf16-rounded C times *c_f8_scale
+     * (saturating; c_f8_fmt OCC_FP8_E4M3 or OCC_FP8_E5M2), *c_f8_amax = max(*c_f8_amax, |C|).  Needs c_dtype bf16, no residual,
+     * N % 8 == 0 and a launch that takes the 256-row kernel (else OCC_EUNSUPPORTED); NULL = off.                              */
+    void* c_f8; const float* c_f8_scale; float* c_f8_amax; int c_f8_fmt;
 } occ_gemm_desc;
 /* C = act(alpha * A.W^T + bias) + R.  Replaces every nn.Linear / Conv1d of the path
  * (fairseq wav2vec2 layers reached from sslassist.py:48; AModel.LL sslassist.py:509).             */

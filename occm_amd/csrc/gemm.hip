@@ -593,6 +593,10 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     a.act = d->act; a.alpha = d->alpha; a.aux = (unsigned short*)d->aux;
     a.dq_a = fp8 ? d->a_dequant : nullptr; a.dq_w = fp8 ? d->w_dequant : nullptr;
     a.ksplit = 1; a.slabs_per_split = 0; a.ngroups = 1;
+    a.f8_out = (unsigned char*)d->c_f8; a.f8_scale = d->c_f8_scale; a.f8_amax = d->c_f8_amax; a.f8_e5m2 = d->c_f8_fmt == OCC_FP8_E5M2;
+    OCC_CHECK_ARG(!d->c_f8 || (d->c_dtype == OCC_BF16 && !d->R && d->N % 8 == 0 && d->c_f8_scale && (d->c_f8_fmt == OCC_FP8_E4M3 || d->c_f8_fmt == OCC_FP8_E5M2)),
+                  "occ_gemm: c_f8 needs a bf16 result, no residual, N %% 8 == 0, a scale and an fp8 format");
+    OCC_CHECK_ARG(!d->c_f8 || (rows_epilogue_applies(a) && d->c_map.rows_per_line == 0 && d->c_map.rows_per_batch >= d->M), "occ_gemm: c_f8 needs one of the row-epilogue forms and a plain C row map");
     a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
     a.tile_rows = TM;
     // grouped tile order (8 m-tiles per W panel) measured +3 % on the N >= 3072 front-end GEMMs and +10 % at 4096^3, -2 % at N = 1024
@@ -641,7 +645,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         const long long nbn256 = occ_cdiv(d->N, 256), tiles = nbm256 * nbn256, cus = cu_count(), rem = tiles % cus;
         long long oa = 0, oc = 0, orr = 0;
         const long long nbm1 = (tiles - rem) / nbn256, m1 = nbm1 * 256;
-        const bool can_tail = variant == 1 && tail_env && tiles > cus && rem > 0 && rem * 2 <= cus && nbm1 >= 1 && nbm1 < nbm256 &&
+        const bool can_tail = !d->c_f8 && variant == 1 && tail_env && tiles > cus && rem > 0 && rem * 2 <= cus && nbm1 >= 1 && nbm1 < nbm256 &&
                               rows_rebase(d->a_map, d->M, m1, &oa) && rows_rebase(d->c_map, d->M, m1, &oc) && (!d->R || rows_rebase(d->r_map, d->M, m1, &orr));
         const bool can_224 = rows_epilogue_applies(a) && (variant == 31 || (variant == 1 && r224_env));
         const long long cost_whole = occ_cdiv(tiles, cus) * 256, cost_tail = can_tail ? (tiles / cus) * 256 + 200 : (1ll << 40),
@@ -672,6 +676,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         OCC_LAUNCH_CHECK("occ_gemm");
         return OCC_OK;
     }
+    if (d->c_f8) { occ_set_error("occ_gemm: c_f8 is written by the 256-row kernel's epilogue only; this launch (M=%ld N=%ld K=%ld) does not take it", (long)d->M, (long)d->N, (long)d->K); return OCC_EUNSUPPORTED; }
     g_last_kernel = OCC_GEMM_KERNEL_OTHER;
     if (d->ab_dtype == OCC_BF16 && d->K % 128 == 0 && variant == 22) {
         hipLaunchKernelGGL(gemm_bf16_ks2_kernel, dim3((unsigned)total, (unsigned)ng), dim3(512), 0, s, a);

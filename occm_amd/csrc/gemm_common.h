@@ -23,6 +23,7 @@ struct GemmArgs {
     int act; float alpha;
     const float* dq_a; const float* dq_w;   // fp8 operands: device scalars that undo the per-tensor quantisation scales (alpha *= *dq_a * *dq_w), or null
     unsigned short* aux;
+    unsigned char* f8_out; const float* f8_scale; float* f8_amax; int f8_e5m2;   // optional fp8 copy of a bf16 result (row epilogue of the 256-row kernel)
     int nbm, nbn;
     int group_m;              // >0: walk GROUP_M m-tiles per n-tile before moving on (L2-sized working set), 0: n fastest
     long long a_gstride, w_gstride, c_gstride;
@@ -230,6 +231,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
         const bool whole = n + 8 <= a.N;
         if (HASB && n < a.N) { b0 = *reinterpret_cast<const f32x4*>(a.bias + n); if (whole) b1 = *reinterpret_cast<const f32x4*>(a.bias + n + 4); }
         const long long nld = n + 8 <= a.N ? n : (a.N >= 8 ? a.N - 8 : 0);        // a column group that lies inside the row (its values are unused when n is not whole)
+        float f8max = 0.f;
+        const float f8sc = a.f8_out && a.f8_scale ? *a.f8_scale : 1.f;
         uint4 ux[4];                               // this chunk's four side-tensor vectors; slot k is refilled for the next chunk right after its use
         auto load_aux = [&](const int ch, const int k) {
             long long m = mrow0 + ch * 32 + k * 8 + rr; if (m > a.M - 1) m = a.M - 1;
@@ -280,7 +283,31 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
                 uint4 o; pack(o);
                 if (whole) *reinterpret_cast<uint4*>(a.C + coff * 2) = o;
                 else *reinterpret_cast<uint2*>(a.C + coff * 2) = make_uint2(o.x, o.y);
+                if (a.f8_out && whole) {            // fp8 of the bf16-rounded values (what a stand-alone quantisation pass would read), saturating
+                    const unsigned w8[4] = {o.x, o.y, o.z, o.w};
+                    float qv[8];
+                    const float lim = a.f8_e5m2 ? 57344.f : 448.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __uint_as_float(w8[e] << 16), hi = __uint_as_float(w8[e] & 0xffff0000u);
+                        f8max = fmaxf(f8max, fmaxf(fabsf(lo), fabsf(hi)));
+                        qv[2 * e] = fminf(fmaxf(lo * f8sc, -lim), lim); qv[2 * e + 1] = fminf(fmaxf(hi * f8sc, -lim), lim);
+                    }
+                    int q0, q1;
+                    if (a.f8_e5m2) {
+                        q0 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[0], qv[1], 0, false); q1 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[4], qv[5], 0, false);
+                        q0 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[2], qv[3], q0, true); q1 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[6], qv[7], q1, true);
+                    } else {
+                        q0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[0], qv[1], 0, false); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[4], qv[5], 0, false);
+                        q0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[2], qv[3], q0, true); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[6], qv[7], q1, true);
+                    }
+                    *reinterpret_cast<uint2*>(a.f8_out + m * a.N + n) = make_uint2((unsigned)q0, (unsigned)q1);
+                }
             }
+        }
+        if (a.f8_out && a.f8_amax) {                // one guarded atomic per wave (non-negative floats order as their bit patterns)
+            f8max = wave_max(f8max);
+            if (lane == 0 && f8max > __hip_atomic_load(a.f8_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(reinterpret_cast<unsigned*>(a.f8_amax), __float_as_uint(f8max));
         }
         return;
     }

@@ -527,7 +527,7 @@ class XlsrFineTuner(XlsrFrontend):
         z = lambda k: torch.zeros(k, device=dev, dtype=torch.float32)
         self.f8 = {"e4": OCC_FP8_E4M3, "e5": OCC_FP8_E5M2, "margin": margin, "warm": True,
                    "amax4": z(n * 8), "scale4": torch.ones(n * 8, device=dev), "inv4": torch.ones(n * 8, device=dev),
-                   "amax5": z(n * 4), "scale5": torch.ones(n * 4, device=dev), "inv5": torch.ones(n * 4, device=dev), "wq": {}, "wtq": {}, "qa": None, "qg": None}
+                   "amax5": z(n * 4), "scale5": torch.ones(n * 4, device=dev), "inv5": torch.ones(n * 4, device=dev), "wq": {}, "wtq": {}, "qa": None, "qg": None, "qa1": None, "qg1": None}
         for i in range(n):
             for wn in ("qkv.w", "o.w", "fc1.w", "fc2.w"):
                 name = "l%d.%s" % (i, wn)
@@ -567,40 +567,57 @@ class XlsrFineTuner(XlsrFrontend):
         ops.fp8_quantize(x, q, fmt, scale=sc[k:k + 1], amax=am[k:k + 1])
         return q, inv[k:k + 1]
 
-    def _lin(self, i, wn, a, site, M, N, K, C, c_map, c_dtype, **kw):
-        """Forward Linear of layer i (weight "l<i>.<wn>", input a [M,K] bf16): bf16 MFMA, or fp8 with the site's delayed scale."""
+    def _lin(self, i, wn, a, site, M, N, K, C, c_map, c_dtype, f8_next=None, **kw):
+        """Forward Linear of layer i (weight "l<i>.<wn>", input a [M,K] bf16): bf16 MFMA, or fp8 with the site's delayed scale.
+        f8_next (fp8 path, delayed scales known): the activation site whose e4m3 operand is this GEMM's bf16 result -- the epilogue then
+        writes it (other operand buffer) and the consumer skips its quantisation pass."""
         name = "l%d.%s" % (i, wn)
         if not getattr(self, "fp8", False):
             ops.gemm_raw(M, N, K, a, rowmap(M, 0, K), self.w[name], K, C, c_map, c_dtype, OCC_BF16_CODE, **kw)
             return
         k4 = i * 8 + self._E4[site]
-        if self._f8_pre == (4, k4):                               # the producing kernel (LayerNorm) already wrote the e4m3 operand
-            q, inv_a = self.f8["qa"][: a.numel()], self.f8["inv4"][k4:k4 + 1]
+        if self._f8_pre is not None and self._f8_pre[:2] == (4, k4):      # the producing kernel already wrote the e4m3 operand
+            slot = self._f8_pre[2]
+            q, inv_a = self._f8_buf(4, a.numel(), slot), self.f8["inv4"][k4:k4 + 1]
         else:
+            slot = 0
             q, inv_a = self._fp8_q(a, 4, k4)
         self._f8_pre = None
         kw_ = i * 8 + self._E4[wn]
+        if f8_next is not None and not self.f8["warm"] and M >= 256 and N >= 256:
+            kn = i * 8 + self._E4[f8_next]
+            kw["c_f8"] = (self._f8_buf(4, M * N, 1 - slot), self.f8["scale4"][kn:kn + 1], self.f8["amax4"][kn:kn + 1], self.f8["e4"])
+            self._f8_pre = (4, kn, 1 - slot)
         ops.gemm_raw(M, N, K, q, rowmap(M, 0, K), self.f8["wq"][name], K, C, c_map, c_dtype, self.f8["e4"], a_dequant=inv_a, w_dequant=self.f8["inv4"][kw_:kw_ + 1], **kw)
 
-    def _dgrad(self, i, wn, dy, gsite, M, N, K, C, **kw):
-        """Input gradient dX [M,N] = dY [M,K] . W (through W^T [N,K]) of layer i's weight wn."""
+    def _dgrad(self, i, wn, dy, gsite, M, N, K, C, f8_next=None, **kw):
+        """Input gradient dX [M,N] = dY [M,K] . W (through W^T [N,K]) of layer i's weight wn.  f8_next: the gradient site whose e5m2 operand
+        is this GEMM's bf16 result (as in _lin)."""
         name = "l%d.%s" % (i, wn)
         if not getattr(self, "fp8", False):
             ops.gemm_raw(M, N, K, dy, rowmap(M, 0, K), self.wT[name], K, C, rowmap(M, 0, N), OCC_BF16_CODE, OCC_BF16_CODE, **kw)
             return
         k5 = i * 4 + self._E5[gsite]
-        if self._f8_pre == (5, k5):                               # the producing kernel (LayerNorm backward) already wrote the e5m2 operand
-            q, inv_g = self.f8["qg"][: dy.numel()], self.f8["inv5"][k5:k5 + 1]
+        if self._f8_pre is not None and self._f8_pre[:2] == (5, k5):      # the producing kernel already wrote the e5m2 operand
+            slot = self._f8_pre[2]
+            q, inv_g = self._f8_buf(5, dy.numel(), slot), self.f8["inv5"][k5:k5 + 1]
         else:
+            slot = 0
             q, inv_g = self._fp8_q(dy, 5, k5)
         self._f8_pre = None
         kw_ = i * 8 + self._E4[wn]
+        if f8_next is not None and not self.f8["warm"] and M >= 256 and N >= 256:
+            kn = i * 4 + self._E5[f8_next]
+            kw["c_f8"] = (self._f8_buf(5, M * N, 1 - slot), self.f8["scale5"][kn:kn + 1], self.f8["amax5"][kn:kn + 1], self.f8["e5"])
+            self._f8_pre = (5, kn, 1 - slot)
         ops.gemm_raw(M, N, K, q, rowmap(M, 0, K), self.f8["wtq"][name], K, C, rowmap(M, 0, N), OCC_BF16_CODE, self.f8["e5"], a_dequant=inv_g,
                      w_dequant=self.f8["inv4"][kw_:kw_ + 1], **kw)
 
-    def _f8_buf(self, kind, numel):
-        key = "qa" if kind == 4 else "qg"
-        if self.f8[key] is None or self.f8[key].numel() < numel:
+    def _f8_buf(self, kind, numel, slot=0):
+        """fp8 operand scratch: two buffers per kind (4 = e4m3 activations, 5 = e5m2 gradients) -- a GEMM that reads its fp8 operand from one
+        can write the fp8 copy of its own result (the next GEMM's operand) into the other."""
+        key = ("qa" if kind == 4 else "qg") + ("" if slot == 0 else "1")
+        if self.f8.get(key) is None or self.f8[key].numel() < numel:
             self.f8[key] = torch.empty(numel, device=self.device, dtype=torch.uint8)
         return self.f8[key][:numel]
 
@@ -611,7 +628,7 @@ class XlsrFineTuner(XlsrFrontend):
         if getattr(self, "fp8", False) and not self.f8["warm"]:
             k4 = i * 8 + self._E4[site]
             ops.layernorm_fp8(x, g, b, out, self._f8_buf(4, out.numel()), self.f8["scale4"][k4:k4 + 1], self.f8["amax4"][k4:k4 + 1])
-            self._f8_pre = (4, k4)
+            self._f8_pre = (4, k4, 0)
         else:
             ops.layernorm(x, g, b, out=out)
 
@@ -628,7 +645,7 @@ class XlsrFineTuner(XlsrFrontend):
                                     dbias=self.mg[bias_name] if bias_name is not None else None, dx_f8=q,
                                     f8_scale=self.f8["scale5"][f8_site:f8_site + 1] if f8 else None, f8_amax=self.f8["amax5"][f8_site:f8_site + 1] if f8 else None)
             if f8:
-                self._f8_pre = (5, f8_site)
+                self._f8_pre = (5, f8_site, 0)
             return bias_name is not None
         ops.layernorm_bwd(dy, x, self.w[gname + ".g"], dres, dx, self.mg[gname + ".g"], self.mg[gname + ".b"], dx_bf16=dxb)
         return False
@@ -723,7 +740,8 @@ class XlsrFineTuner(XlsrFrontend):
             else:
                 self._lin(i, "o.w", s["att"], "att", M, D, D, x_mid, xmap, OCC_F32, bias=w["l%d.o.b" % i], R=x_in, r_map=xmap, r_dtype=OCC_F32)
             self._ln_fwd(i, x_mid, "ln2", s["h2"], "h2")
-            self._lin(i, "fc1.w", s["h2"], "h2", M, Fd, D, s["f"], rowmap(M, 0, Fd), code, bias=w["l%d.fc1.b" % i], act=ACT_GELU, aux=s["u"])
+            self._lin(i, "fc1.w", s["h2"], "h2", M, Fd, D, s["f"], rowmap(M, 0, Fd), code, bias=w["l%d.fc1.b" % i], act=ACT_GELU, aux=s["u"],
+                      f8_next="f" if p_act == 0 else None)
             if p_act > 0:                                        # dropout2 on the activation
                 self._drop_fwd("l%d.act" % i, s["f"], s["f"], p_act)
             if p_res > 0:                                        # x = residual + dropout3(fc2(.))
@@ -826,7 +844,7 @@ class XlsrFineTuner(XlsrFrontend):
             dyb = dxb
             if p_res > 0:
                 dyb = tr["dyb"]; self._drop_bwd("l%d.d3" % i, dxb, dyb, p_res)
-            self._dgrad(i, "fc2.w", dyb, "g_fc2", M, Fd, D, tr["du"], act=ACT_GELU_GRAD, aux=s["u"])
+            self._dgrad(i, "fc2.w", dyb, "g_fc2", M, Fd, D, tr["du"], act=ACT_GELU_GRAD, aux=s["u"], f8_next="g_fc1" if p_act == 0 else None)
             if p_act > 0:                                        # (elementwise factors commute: mask after GELU')
                 self._drop_bwd("l%d.act" % i, tr["du"], tr["du"], p_act)
             # both FFN weight gradients in one launch (dyb is not rewritten before the LayerNorm backward below)

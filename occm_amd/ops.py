@@ -28,7 +28,7 @@ def rowmap(rows_per_batch, batch_stride, row_stride, rows_per_line=0, line_strid
 
 
 def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, act=ACT_NONE, alpha=1.0,
-             R=None, r_map=None, r_dtype=OCC_F32, a_seg=None, groups=None, aux=None, a_dequant=None, w_dequant=None):
+             R=None, r_map=None, r_dtype=OCC_F32, a_seg=None, groups=None, aux=None, a_dequant=None, w_dequant=None, c_f8=None):
     """Direct descriptor-level call.  A/W/C/R/bias are ints (device addresses) or tensors."""
     d = GemmDesc()
     d.M, d.N, d.K = int(M), int(N), int(K)
@@ -59,6 +59,8 @@ def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, 
         d.a_dequant = a_dequant if isinstance(a_dequant, int) else a_dequant.data_ptr()
     if w_dequant is not None:
         d.w_dequant = w_dequant if isinstance(w_dequant, int) else w_dequant.data_ptr()
+    if c_f8 is not None:                       # (u8 buffer, scale scalar, amax scalar, fp8 format): fp8 copy of the bf16 result from the same epilogue
+        d.c_f8, d.c_f8_scale, d.c_f8_amax, d.c_f8_fmt = c_f8[0].data_ptr(), c_f8[1].data_ptr(), c_f8[2].data_ptr(), int(c_f8[3])
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -439,13 +441,30 @@ class AdamMulti:
         self._g_host = None
         self._g = None
 
-    def step(self, grads, grad_scale=1.0):
-        """grads: list aligned with params (None = no gradient)."""
+    def _grad_table(self, grads):
         ptrs = [0 if g is None else g.data_ptr() for g in grads]
         if self._g_host != ptrs:
             self._g_host = ptrs
             self._g = torch.tensor(ptrs, dtype=torch.int64, device=self.params[0].device)
+
+    def step(self, grads, grad_scale=1.0):
+        """grads: list aligned with params (None = no gradient)."""
+        self.set_grads(grads)
+        self.step_range(0, len(self.params), grad_scale)
+
+    def set_grads(self, grads):
+        """Registers the gradient tensors of this optimizer step for step_range()."""
+        self._grad_table(grads)
         self.step_count += 1
-        check(lib().occ_adam_multi(ptr(self._p), ptr(self._g), ptr(self._m), ptr(self._v), ptr(self._sizes), ptr(self._steps),
-                                   len(self.params), self._max, self.lr, self.betas[0], self.betas[1], self.eps, float(grad_scale),
-                                   ptr(self._b), stream_ptr()), "occ_adam_multi")
+
+    def step_range(self, first, count, grad_scale=1.0):
+        """The update of tensors [first, first + count) only, on the current stream: an overlapped trainer updates a transformer layer as
+        soon as its gradients are final.  Every tensor must be stepped exactly once per optimizer step, after one set_grads()."""
+        if count <= 0:
+            return
+        off8, off4 = first * 8, first * 4
+        P = lambda t, o: ctypes.c_void_p(t.data_ptr() + o)
+        mx = max(p.numel() for p in self.params[first:first + count])
+        check(lib().occ_adam_multi(P(self._p, off8), P(self._g, off8), P(self._m, off8), P(self._v, off8), P(self._sizes, off8), P(self._steps, off4),
+                                   count, mx, self.lr, self.betas[0], self.betas[1], self.eps, float(grad_scale),
+                                   P(self._b, off8) if self._b is not None else None, stream_ptr()), "occ_adam_multi")

@@ -78,16 +78,20 @@ class FlatGradAllReducer:
             _cast(self.flat[lo:hi], self._stage[lo:hi])       # on the compute stream, behind the kernels that produced the slice
             self._pending.append((lo, hi))
         buf = self.flat if self.wire is None else self._stage
+        mine = []
         for a in range(lo, hi, self.bucket):
             b = min(a + self.bucket, hi)
-            self._works.append(dist.all_reduce(buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            mine.append(dist.all_reduce(buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._works += mine
+        return mine
 
     def reduce_range(self, lo, hi):
-        """Gradients in flat[lo:hi] are final: start their all-reduce now (no-op on one rank)."""
+        """Gradients in flat[lo:hi] are final: start their all-reduce now (no-op on one rank).  Returns the collective's work handles
+        (f32 wire only; a caller that wants to consume the slice early waits on them on its own stream)."""
         if self.world == 1 or hi <= lo:
-            return
+            return []
         self._started.append((int(lo), int(hi)))
-        self._launch(int(lo), int(hi))
+        return self._launch(int(lo), int(hi))
 
     def all_reduce(self, async_op=False):
         if self.world == 1:

@@ -38,11 +38,31 @@ class OcTrainer:
         self.w_c, self.w_d = w_compact, w_descr
         self.group_size = group_size
         params, self._grads, mirrors = [self.be.P], [self.be.G], [None]
+        flat = [self.be.G]
+        self._chunk_of = {}
         if train_frontend:                     # XLS-R is trained: its bf16 GEMM operands are written by the optimizer kernel itself
-            params.append(self.fe.P); self._grads.append(self.fe.G); mirrors.append(getattr(self.fe, "Wb", None))
+            fe = self.fe
+            flat.append(fe.G)
+            Wb = getattr(fe, "Wb", None)
+            if hasattr(fe, "layer_grad_range") and Wb is not None:
+                # one optimizer "tensor" per transformer layer (its twelve tensors are one contiguous slice of the flat buffers) + the rest:
+                # a layer is updated on a side stream as soon as its gradients are final, under the remaining backward pass
+                cuts = [fe.layer_grad_range(i) for i in range(fe.cfg.layers)]
+                assert cuts[0][0] == 0 and all(cuts[i][1] == cuts[i + 1][0] for i in range(len(cuts) - 1))
+                cuts.append((cuts[-1][1], fe.P.numel()))
+                for lo, hi in cuts:
+                    self._chunk_of[(lo, hi)] = len(params)
+                    params.append(fe.P[lo:hi]); self._grads.append(fe.G[lo:hi]); mirrors.append(Wb[lo:hi])
+            else:
+                params.append(fe.P); self._grads.append(fe.G); mirrors.append(Wb)
         self.opt = ops.AdamMulti(params, lr=lr, bf16_copies=mirrors)
+        import os
+        # Off by default: measured on one MI355X (bench.py, configs[2]) the per-layer Adam launches on a second stream slowed the GEMMs they
+        # ran beside by as much as they hid (51.70 vs 51.68 / 52.38 ms per step, GEMM family 32.0 -> 33.4 ms); OCC_OPT_OVERLAP=1 enables it.
+        self.overlap_optimizer = os.environ.get("OCC_OPT_OVERLAP", "0") == "1"
+        self._opt_stream = None
         # grad_wire_dtype=torch.bfloat16: the XLS-R gradients (1.26 GB f32) cross xGMI as bf16; the small back-end buffer stays f32
-        self.reducers = [FlatGradAllReducer(g, wire_dtype=grad_wire_dtype if i == 1 else None) for i, g in enumerate(self._grads)]
+        self.reducers = [FlatGradAllReducer(g, wire_dtype=grad_wire_dtype if i == 1 else None) for i, g in enumerate(flat)]
         self.reducer = self.reducers[0]
         self.last = None
         # frozen front-end: features of the NEXT batch can be computed on a side stream while the back-end trains on this one
@@ -199,10 +219,47 @@ class OcTrainer:
         lc, ld, dfeats = self._backend_section(feats, labels, True)
         # each transformer layer's 50 MB of gradients go to RCCL as soon as that layer's backward is enqueued (last layer first);
         # the conv stack, the back-end and anything left over follow at the end
-        fe.backward(dfeats, grad_ready=self.reducers[1].reduce_range if self.reducers[1].world > 1 else None)
+        # ... and the optimizer follows layer by layer: as soon as a layer's gradients are final (and, with several ranks, summed) its Adam
+        # update -- HBM-bound, 30 B per parameter -- runs on its own stream beside the MFMA-bound backward of the layers below.  A layer's
+        # f32 masters / bf16 forward operands are not read again in this step (backward multiplies by the transposed copies, which are
+        # refreshed after the step), and the gradient slices are disjoint.
+        red = self.reducers[1]
+        scale = self.reducer.grad_scale
+        overlap = self.overlap_optimizer and bool(self._chunk_of) and red.wire is None
+        self.opt.set_grads(self._grads)
+        stepped = set()
+        if overlap and self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=wav.device)
+
+        def ready(lo, hi):
+            works = red.reduce_range(lo, hi)
+            idx = self._chunk_of.get((lo, hi)) if overlap else None
+            if idx is None or idx in stepped:
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(self._opt_stream):
+                self._opt_stream.wait_event(ev)
+                for w in works:
+                    w.wait()                                   # (stream-ordered for RCCL: the optimizer stream waits, not the host)
+                self.opt.step_range(idx, 1, scale)
+            stepped.add(idx)
+
+        fe.backward(dfeats, grad_ready=ready if (overlap or red.world > 1) else None)
         for r in self.reducers:
             r.all_reduce()
-        self.opt.step(self._grads, grad_scale=self.reducer.grad_scale)
+        n, i = len(self.opt.params), 0
+        while i < n:                                             # everything not updated yet, in runs of consecutive tensors
+            if i in stepped:
+                i += 1
+                continue
+            j = i
+            while j < n and j not in stepped:
+                j += 1
+            self.opt.step_range(i, j - i, scale)
+            i = j
+        if stepped:
+            main.wait_stream(self._opt_stream)
         fe.refresh_operands(cast=not hasattr(fe, "Wb"))
         self.last = (lc, ld)
         return lc, ld

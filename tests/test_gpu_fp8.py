@@ -139,3 +139,40 @@ def test_finetuner_fp8_path_against_bf16_path_and_oracle():
     d2 = (o8b - o8).abs()
     assert float(d2.max()) < 0.3, float(d2.max())                 # same input, same weights: only the (now delayed) scales may differ slightly
     assert float(ft8.f8["amax4"].max()) > 0                        # and this step's |max| is being recorded for the next one
+
+
+@pytest.mark.parametrize("kind", ["gelu_aux_e4m3", "gelu_grad_e5m2", "plain_e4m3"])
+def test_gemm_epilogue_writes_the_fp8_copy_of_its_bf16_result(kind):
+    """occ_gemm c_f8: the 256-row kernel's row epilogue also writes fp8(bf16 result * scale) and raises |max| -- bit-identical to
+    occ_fp8_quantize run over the bf16 result afterwards (same scale), for the fc1 form (bias + GELU + saved pre-activation, e4m3), the
+    fc2-input-gradient form (GELU' from the saved pre-activation, e5m2) and a plain one; fp8 operands as on the configs[4] path."""
+    from occm_amd import ops
+    from occm_amd._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, OCC_BF16, OCC_FP8_E4M3, OCC_FP8_E5M2
+    M, N, K = 1531, 1024, 512
+    g = torch.Generator().manual_seed(9)
+    a8 = (torch.randn(M, K, generator=g) * 0.5).to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    w8 = (torch.randn(N, K, generator=g) * 0.3).to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    dq = torch.tensor([0.5], device="cuda")
+    bias = torch.randn(N, generator=g).cuda()
+    fmt = OCC_FP8_E5M2 if kind.endswith("e5m2") else OCC_FP8_E4M3
+    kw = {}
+    if kind == "gelu_aux_e4m3":
+        kw = dict(bias=bias, act=ACT_GELU, aux=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
+    elif kind == "gelu_grad_e5m2":
+        kw = dict(act=ACT_GELU_GRAD, aux=torch.randn(M, N, generator=g).bfloat16().cuda())
+    else:
+        kw = dict(bias=bias)
+    C0, C1 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    run = lambda C, **extra: ops.gemm_raw(M, N, K, a8, ops.rowmap(M, 0, K), w8, K, C, ops.rowmap(M, 0, N), OCC_BF16, OCC_FP8_E4M3, a_dequant=dq, w_dequant=dq, **kw, **extra)
+    run(C0)
+    scale, amax0, amax1 = torch.tensor([23.0], device="cuda"), torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    q0, q1 = torch.empty(M * N, device="cuda", dtype=torch.uint8), torch.zeros(M * N, device="cuda", dtype=torch.uint8)
+    ops.fp8_quantize(C0, q0, fmt, scale=scale, amax=amax0)
+    run(C1, c_f8=(q1, scale, amax1, fmt))
+    assert torch.equal(C1, C0) and torch.equal(q1, q0) and float(amax1) == float(amax0) > 0
+    # a launch that cannot take the 256-row kernel refuses instead of silently skipping the copy
+    from occm_amd._lib import OccError
+    small = torch.empty(64, N, device="cuda", dtype=torch.bfloat16)
+    x16 = torch.randn(64, K, generator=g).bfloat16().cuda(); w16 = torch.randn(N, K, generator=g).bfloat16().cuda()
+    with pytest.raises(OccError):
+        ops.gemm_raw(64, N, K, x16, ops.rowmap(64, 0, K), w16, K, small, ops.rowmap(64, 0, N), OCC_BF16, OCC_BF16, c_f8=(q1, scale, amax1, fmt))
