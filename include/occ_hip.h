@@ -141,6 +141,11 @@ typedef struct occ_gemm_desc {
      * (saturating; c_f8_fmt OCC_FP8_E4M3 or OCC_FP8_E5M2), *c_f8_amax = max(*c_f8_amax, |C|).  Needs c_dtype bf16, no residual,
      * N % 8 == 0 and a launch that takes the 256-row kernel (else OCC_EUNSUPPORTED); NULL = off.                              */
     void* c_f8; const float* c_f8_scale; float* c_f8_amax; int c_f8_fmt;
+    /* Optional column sums of a bf16 result from the same epilogue: c_colsum f32 [N] += sum over rows of the (bf16-rounded) C -- the
+     * bias gradient of the layer whose output gradient C is (fc1: C = the gradient through GELU), which otherwise is a pass over C.
+     * c_colsum_ws: caller-owned f32 scratch, >= 2 * ceil(M / 224) * N floats (per-tile partial sums, added in a fixed order by a
+     * second small launch).  Same launch restrictions as c_f8.                                                              */
+    float* c_colsum; float* c_colsum_ws; int64_t c_colsum_ws_floats;
 } occ_gemm_desc;
 /* C = act(alpha * A.W^T + bias) + R.  Replaces every nn.Linear / Conv1d of the path
  * (fairseq wav2vec2 layers reached from sslassist.py:48; AModel.LL sslassist.py:509).             */
@@ -427,6 +432,11 @@ int occ_attention_dropout(const void* qkv, void* out, int64_t B, int64_t T, int6
 int occ_attention_bwd_dropout(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T,
                               int64_t H, int64_t hd, int64_t ld_qkv, int64_t ld_o, float scale, float* dq_accum, const uint8_t* keep,
                               float p, void* stream);
+/* occ_attention_bwd for T <= 256 that also accumulates the q|k|v bias gradient: dbias f32 [3D] += column sums of the (bf16) dqkv it
+ * writes -- the separate pass over dqkv folded into the kernel that produces it.  bias_ws: f32 scratch >= B*H*3*hd floats.       */
+int occ_attention_bwd_bias(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H,
+                           int64_t hd, int64_t ld_qkv, int64_t ld_o, float scale, float* dbias, float* bias_ws, int64_t bias_ws_floats,
+                           void* stream);
 /* dq|dk|dv (bf16 [B*T, 3D], same layout as qkv) of softmax(scale q.k^T) v given o (forward output), dout and the forward's lse.
  * head_dim 64 or 80, any T.  T > 256 needs dq_accum: caller-owned f32 scratch [B*T, H*hd] (16-byte aligned) in which the key blocks
  * of a head meet; it may be NULL for T <= 256.                                                                   */

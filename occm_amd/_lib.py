@@ -34,7 +34,8 @@ class GemmDesc(ctypes.Structure):
                 ("n_groups", ctypes.c_int64), ("a_group_stride", ctypes.c_int64),
                 ("w_group_stride", ctypes.c_int64), ("c_group_stride", ctypes.c_int64), ("aux", ctypes.c_void_p),
                 ("a_dequant", ctypes.c_void_p), ("w_dequant", ctypes.c_void_p),
-                ("c_f8", ctypes.c_void_p), ("c_f8_scale", ctypes.c_void_p), ("c_f8_amax", ctypes.c_void_p), ("c_f8_fmt", ctypes.c_int)]
+                ("c_f8", ctypes.c_void_p), ("c_f8_scale", ctypes.c_void_p), ("c_f8_amax", ctypes.c_void_p), ("c_f8_fmt", ctypes.c_int),
+                ("c_colsum", ctypes.c_void_p), ("c_colsum_ws", ctypes.c_void_p), ("c_colsum_ws_floats", ctypes.c_int64)]
 
 
 class GemmTnDesc(ctypes.Structure):

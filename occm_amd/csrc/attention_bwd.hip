@@ -46,12 +46,13 @@ template <int HD> __device__ __forceinline__ unsigned ab_off(int r, int c) {
 
 // DROP (attention_dropout, see occ_attention_dropout): with O = (P o keep / (1-p)) V the forward's O already carries the mask, so
 // delta = rowsum(dO o O) is unchanged; dV uses the dropped probabilities, dP is masked and scaled the same way before dS = P o (dP - delta).
-template <int HD, bool DROP = false>
+template <int HD, bool DROP = false, bool BIAS = false>
 __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ o,
                                                                const unsigned short* __restrict__ dout, const float* __restrict__ lse,
                                                                unsigned short* __restrict__ dqkv, float* __restrict__ dq_accum, int Tn, int H,
                                                                long long ld_qkv, long long ld_o, float scale,
-                                                               const unsigned char* __restrict__ keep = nullptr, int Tp = 0, float inv_keep = 1.f) {
+                                                               const unsigned char* __restrict__ keep = nullptr, int Tp = 0, float inv_keep = 1.f,
+                                                               float* __restrict__ bsum = nullptr) {
     using C = AbCfg<HD>;
     constexpr int KS = C::KS, DT = C::DT, CH = C::CH, ROWB = C::ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -166,8 +167,12 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
     // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q] of one step: 2 q tiles x DT d tiles, dealt round-robin to the 8 waves.  It runs one
     // step late (after the barrier that opens the next step, from the other dS buffer), so a step has ONE workgroup barrier: while some
     // waves add up dQ of step st-1, others are already multiplying S / dP of step st.
+    // bsum (one key block only): per (batch, head) column sums of the stored (bf16-rounded) dq / dk / dv -- the q|k|v bias gradients,
+    // which were a separate pass over dqkv.  dq: this wave's (q tile, d tile) pairs accumulate over the steps.
+    f32x4 dqs[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     auto dq_phase = [&](const int q0, const unsigned short* dSs) {
-        for (int pr = wave; pr < 2 * DT; pr += 8) {
+        int slot = 0;
+        for (int pr = wave; pr < 2 * DT; pr += 8, ++slot) {
             const int qt = pr / DT, dt = pr - qt * DT;
             f32x4 qacc = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int nks = (nkeys + 31) >> 5;
@@ -200,6 +205,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
                     ov.x = (unsigned)f32_to_bf16_bits(qacc[0] * scale) | ((unsigned)f32_to_bf16_bits(qacc[1] * scale) << 16);
                     ov.y = (unsigned)f32_to_bf16_bits(qacc[2] * scale) | ((unsigned)f32_to_bf16_bits(qacc[3] * scale) << 16);
                     *reinterpret_cast<uint2*>(dqkv + ((size_t)b * Tn + q) * ld_qkv + (size_t)h * HD + dt * 16 + g * 4) = ov;
+                    if (BIAS) {
+                        dqs[slot & 1][0] += __uint_as_float(ov.x << 16); dqs[slot & 1][1] += __uint_as_float(ov.x & 0xffff0000u);
+                        dqs[slot & 1][2] += __uint_as_float(ov.y << 16); dqs[slot & 1][3] += __uint_as_float(ov.y & 0xffff0000u);
+                    }
                 } else {
                     float* ap = dq_accum + ((size_t)b * Tn + q) * D + (size_t)h * HD + dt * 16 + g * 4;
 #pragma unroll
@@ -297,6 +306,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
     __syncthreads();
     dq_phase((nstep - 1) * 32, dSs0 + ((nstep - 1) & 1) * 32 * AB_DS_STRIDE);
     // ---- dK, dV of this wave's keys: lane holds 4 consecutive d of one key
+    f32x4 dks[BIAS ? DT : 1], dvs[BIAS ? DT : 1];
+#pragma unroll
+    for (int dt = 0; dt < (BIAS ? DT : 1); ++dt) { dks[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvs[dt] = dks[dt]; }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int key = (wave + 8 * kk) * 16 + fr;
@@ -312,8 +324,60 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
             vv.y = (unsigned)f32_to_bf16_bits(dvacc[dt][kk][2]) | ((unsigned)f32_to_bf16_bits(dvacc[dt][kk][3]) << 16);
             *reinterpret_cast<uint2*>(dkrow + dt * 16 + g * 4) = kk2;
             *reinterpret_cast<uint2*>(dvrow + dt * 16 + g * 4) = vv;
+            if (BIAS) {
+                dks[dt][0] += __uint_as_float(kk2.x << 16); dks[dt][1] += __uint_as_float(kk2.x & 0xffff0000u);
+                dks[dt][2] += __uint_as_float(kk2.y << 16); dks[dt][3] += __uint_as_float(kk2.y & 0xffff0000u);
+                dvs[dt][0] += __uint_as_float(vv.x << 16); dvs[dt][1] += __uint_as_float(vv.x & 0xffff0000u);
+                dvs[dt][2] += __uint_as_float(vv.y << 16); dvs[dt][3] += __uint_as_float(vv.y & 0xffff0000u);
+            }
         }
     }
+    if (BIAS) {
+        // sums over the 16 keys / queries of a lane row (xor 1, 2, 4, 8), then over the waves through LDS (the slices are free: every
+        // phase that read them lies before the barrier below), added in wave order: reproducible
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(Qs);         // [8 waves][3][HD]
+        for (int idx = tid; idx < 8 * 3 * HD; idx += 512) red[idx] = 0.f;
+        __syncthreads();
+        auto row16 = [](float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); return v; };
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sk = row16(dks[dt][r]), sv = row16(dvs[dt][r]);
+                if (fr == 0) { red[(wave * 3 + 1) * HD + dt * 16 + g * 4 + r] = sk; red[(wave * 3 + 2) * HD + dt * 16 + g * 4 + r] = sv; }
+            }
+        {
+            int slot = 0;
+            for (int pr = wave; pr < 2 * DT; pr += 8, ++slot) {
+                const int dt = pr % DT;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sq = row16(dqs[slot & 1][e]);
+                    if (fr == 0) red[(wave * 3 + 0) * HD + dt * 16 + g * 4 + e] += sq;      // a wave's two pairs may share a d tile only for DT < 4 (not the case: DT = 4, 5)
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 3 * HD; idx += 512) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += red[w * 3 * HD + idx];
+            bsum[((size_t)bh * gridDim.y + kb) * 3 * HD + idx] = t;
+        }
+    }
+}
+
+// qkv bias gradients from the per-(batch, head) sums attention_bwd2_kernel leaves: dbias[which*D + h*HD + d] += sum_b bsum[b*H + h][which][d]
+__global__ void attention_bias_finalize_kernel(const float* __restrict__ bsum, float* __restrict__ dbias, int B, int H, int HD, int nkb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = H * HD;
+    if (i >= 3 * D) return;
+    const int which = i / D, h = (i - which * D) / HD, d = i - which * D - h * HD;
+    float t = 0.f;
+    for (int bb = 0; bb < B; ++bb)
+        for (int k = 0; k < nkb; ++k) t += bsum[(((size_t)bb * H + h) * nkb + k) * 3 * HD + which * HD + d];
+    dbias[i] += t;
 }
 
 // several key blocks: dq (bf16, the q columns of dqkv) = the f32 sums of their parts
@@ -329,18 +393,21 @@ __global__ void attention_dq_finish_kernel(const float* __restrict__ acc, unsign
     }
 }
 
-template <int HD, bool DROP = false>
+template <int HD, bool DROP = false, bool BIAS = false>
 int launch_attention_bwd2(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* dq_accum, int64_t B, int64_t T, int64_t H,
-                          int64_t ld_qkv, int64_t ld_o, float scale, hipStream_t s, const unsigned char* keep = nullptr, float p = 0.f) {
+                          int64_t ld_qkv, int64_t ld_o, float scale, hipStream_t s, const unsigned char* keep = nullptr, float p = 0.f, float* dbias = nullptr,
+                          float* bias_ws = nullptr) {
     using C = AbCfg<HD>;
     const size_t shm = (size_t)AB_KEYS * C::ROWB + 4 * 32 * C::ROWB + 2 * 32 * AB_DS_STRIDE * 2 + 128 * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)attention_bwd2_kernel<HD, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipError_t e = hipFuncSetAttribute((const void*)attention_bwd2_kernel<HD, DROP, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) { occ_set_error("occ_attention_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
     const int64_t nkb = occ_cdiv(T, AB_KEYS);
     if (nkb > 1 && hipMemsetAsync(dq_accum, 0, (size_t)(B * T * H * HD) * sizeof(float), s) != hipSuccess) { occ_set_error("occ_attention_bwd: memset failed"); return OCC_ELAUNCH; }
-    hipLaunchKernelGGL((attention_bwd2_kernel<HD, DROP>), dim3((unsigned)(B * H), (unsigned)nkb), dim3(512), shm, s, (const unsigned short*)qkv, (const unsigned short*)o,
+    hipLaunchKernelGGL((attention_bwd2_kernel<HD, DROP, BIAS>), dim3((unsigned)(B * H), (unsigned)nkb), dim3(512), shm, s, (const unsigned short*)qkv, (const unsigned short*)o,
                        (const unsigned short*)dout, lse, (unsigned short*)dqkv, dq_accum, (int)T, (int)H, (long long)ld_qkv, (long long)ld_o, scale, keep,
-                       (int)((T + 3) / 4 * 4), 1.0f / (1.0f - p));
+                       (int)((T + 3) / 4 * 4), 1.0f / (1.0f - p), dbias ? bias_ws : nullptr);
+    if (dbias)
+        hipLaunchKernelGGL(attention_bias_finalize_kernel, dim3((unsigned)occ_cdiv(3 * H * HD, 256)), dim3(256), 0, s, (const float*)bias_ws, dbias, (int)B, (int)H, HD, (int)nkb);
     if (nkb > 1) {
         long long blocks = occ_cdiv(B * T * (H * HD / 4), 256);
         if (blocks > 4096) blocks = 4096;
@@ -350,6 +417,19 @@ int launch_attention_bwd2(const void* qkv, const void* o, const void* dout, cons
 }
 
 }  // namespace
+
+extern "C" int occ_attention_bwd_bias(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H, int64_t hd,
+                                      int64_t ld_qkv, int64_t ld_o, float scale, float* dbias, float* bias_ws, int64_t bias_ws_floats, void* stream) {
+    OCC_CHECK_ARG(qkv && o && dout && lse && dqkv && dbias && bias_ws, "occ_attention_bwd_bias: null pointer");
+    OCC_CHECK_ARG((hd == 64 || hd == 80) && T >= 1 && T <= AB_KEYS && B >= 1 && H >= 1 && B * H < (1ll << 31), "occ_attention_bwd_bias: head_dim 64 or 80, T <= %d (one key block)", AB_KEYS);
+    OCC_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_qkv >= 3 * H * hd && ld_o >= H * hd && bias_ws_floats >= B * H * 3 * hd, "occ_attention_bwd_bias: leading dimensions / scratch");
+    int rc;
+    if (hd == 64) rc = launch_attention_bwd2<64, false, true>(qkv, o, dout, lse, dqkv, nullptr, B, T, H, ld_qkv, ld_o, scale, (hipStream_t)stream, nullptr, 0.f, dbias, bias_ws);
+    else rc = launch_attention_bwd2<80, false, true>(qkv, o, dout, lse, dqkv, nullptr, B, T, H, ld_qkv, ld_o, scale, (hipStream_t)stream, nullptr, 0.f, dbias, bias_ws);
+    if (rc != OCC_OK) return rc;
+    OCC_LAUNCH_CHECK("occ_attention_bwd_bias");
+    return OCC_OK;
+}
 
 extern "C" int occ_attention_bwd_dropout(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H, int64_t hd,
                                          int64_t ld_qkv, int64_t ld_o, float scale, float* dq_accum, const uint8_t* keep, float p, void* stream) {

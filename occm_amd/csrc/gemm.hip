@@ -533,6 +533,26 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // Rows [m1, M) of a row map as a map of their own: true (and the element offset of row m1) when moving the base pointer does it --
 // no line structure, and m1 either inside the first batch of a single-batch map or on a batch boundary.
+// out[n] += sum over the nrows per-tile partial rows the 256-row kernel's epilogue left (c_colsum), in row order: bit-reproducible
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nrows, long long N, float* __restrict__ out) {
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    int r = 0;
+    for (; r + 8 <= nrows; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long long)(r + u) * N + n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < nrows; ++r) s += part[(long long)r * N + n];
+    out[n] += s;
+}
+static void colsum_finalize(const GemmArgs& a, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)occ_cdiv(a.N, 256)), dim3(256), 0, s, (const float*)a.colsum_part, 2 * a.nbm, a.N, out);
+}
+
 bool rows_rebase(const occ_rowmap& m, long long M, long long m1, long long* off) {
     if (m.rows_per_line > 0 || m.rows_per_batch < 1) return false;
     if (m.rows_per_batch >= M) { *off = m1 * m.row_stride; return true; }
@@ -593,9 +613,13 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     a.act = d->act; a.alpha = d->alpha; a.aux = (unsigned short*)d->aux;
     a.dq_a = fp8 ? d->a_dequant : nullptr; a.dq_w = fp8 ? d->w_dequant : nullptr;
     a.ksplit = 1; a.slabs_per_split = 0; a.ngroups = 1;
+    a.colsum_part = d->c_colsum ? d->c_colsum_ws : nullptr;
+    OCC_CHECK_ARG(!d->c_colsum || (d->c_colsum_ws && ((uintptr_t)d->c_colsum_ws & 15) == 0 && d->c_colsum_ws_floats >= 2 * occ_cdiv(d->M, 224) * d->N && d->c_dtype == OCC_BF16 && !d->R && d->N % 8 == 0),
+                  "occ_gemm: c_colsum needs a bf16 result, no residual, N %% 8 == 0 and 2*ceil(M/224)*N floats of 16-byte aligned scratch");
     a.f8_out = (unsigned char*)d->c_f8; a.f8_scale = d->c_f8_scale; a.f8_amax = d->c_f8_amax; a.f8_e5m2 = d->c_f8_fmt == OCC_FP8_E5M2;
     OCC_CHECK_ARG(!d->c_f8 || (d->c_dtype == OCC_BF16 && !d->R && d->N % 8 == 0 && d->c_f8_scale && (d->c_f8_fmt == OCC_FP8_E4M3 || d->c_f8_fmt == OCC_FP8_E5M2)),
                   "occ_gemm: c_f8 needs a bf16 result, no residual, N %% 8 == 0, a scale and an fp8 format");
+    OCC_CHECK_ARG(!d->c_colsum || (rows_epilogue_applies(a) && d->c_map.rows_per_line == 0 && d->c_map.rows_per_batch >= d->M), "occ_gemm: c_colsum needs one of the row-epilogue forms and a plain C row map");
     OCC_CHECK_ARG(!d->c_f8 || (rows_epilogue_applies(a) && d->c_map.rows_per_line == 0 && d->c_map.rows_per_batch >= d->M), "occ_gemm: c_f8 needs one of the row-epilogue forms and a plain C row map");
     a.nbm = (int)occ_cdiv(d->M, TM); a.nbn = (int)occ_cdiv(d->N, TN);
     a.tile_rows = TM;
@@ -624,6 +648,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         OCC_CHECK_ARG(p8_fits, "occ_gemm: fp8 operands too large for 32-bit DMA offsets");
         g_last_kernel = OCC_GEMM_KERNEL_P8_FP8;
         gemm_p8_launch(a, s, d->ab_dtype == OCC_FP8_E4M3 ? 1 : 2);
+        if (d->c_colsum) colsum_finalize(a, d->c_colsum, s);
         OCC_LAUNCH_CHECK("occ_gemm");
         return OCC_OK;
     }
@@ -645,7 +670,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         const long long nbn256 = occ_cdiv(d->N, 256), tiles = nbm256 * nbn256, cus = cu_count(), rem = tiles % cus;
         long long oa = 0, oc = 0, orr = 0;
         const long long nbm1 = (tiles - rem) / nbn256, m1 = nbm1 * 256;
-        const bool can_tail = !d->c_f8 && variant == 1 && tail_env && tiles > cus && rem > 0 && rem * 2 <= cus && nbm1 >= 1 && nbm1 < nbm256 &&
+        const bool can_tail = !d->c_f8 && !d->c_colsum && variant == 1 && tail_env && tiles > cus && rem > 0 && rem * 2 <= cus && nbm1 >= 1 && nbm1 < nbm256 &&
                               rows_rebase(d->a_map, d->M, m1, &oa) && rows_rebase(d->c_map, d->M, m1, &oc) && (!d->R || rows_rebase(d->r_map, d->M, m1, &orr));
         const bool can_224 = rows_epilogue_applies(a) && (variant == 31 || (variant == 1 && r224_env));
         const long long cost_whole = occ_cdiv(tiles, cus) * 256, cost_tail = can_tail ? (tiles / cus) * 256 + 200 : (1ll << 40),
@@ -654,6 +679,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
             OCC_CHECK_ARG(can_224, "occ_gemm: the 224-row tile has no epilogue for this combination");
             g_last_kernel = OCC_GEMM_KERNEL_P8_224;
             gemm_p8_launch(a, s, 0, 224);
+            if (d->c_colsum) colsum_finalize(a, d->c_colsum, s);
             OCC_LAUNCH_CHECK("occ_gemm");
             return OCC_OK;
         }
@@ -673,9 +699,11 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         }
         g_last_kernel = OCC_GEMM_KERNEL_P8;
         gemm_p8_launch(a, s);
+        if (d->c_colsum) colsum_finalize(a, d->c_colsum, s);
         OCC_LAUNCH_CHECK("occ_gemm");
         return OCC_OK;
     }
+    if (d->c_colsum) { occ_set_error("occ_gemm: c_colsum is produced by the 256-row kernel's epilogue only; this launch (M=%ld N=%ld K=%ld) does not take it", (long)d->M, (long)d->N, (long)d->K); return OCC_EUNSUPPORTED; }
     if (d->c_f8) { occ_set_error("occ_gemm: c_f8 is written by the 256-row kernel's epilogue only; this launch (M=%ld N=%ld K=%ld) does not take it", (long)d->M, (long)d->N, (long)d->K); return OCC_EUNSUPPORTED; }
     g_last_kernel = OCC_GEMM_KERNEL_OTHER;
     if (d->ab_dtype == OCC_BF16 && d->K % 128 == 0 && variant == 22) {

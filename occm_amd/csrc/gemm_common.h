@@ -23,6 +23,7 @@ struct GemmArgs {
     int act; float alpha;
     const float* dq_a; const float* dq_w;   // fp8 operands: device scalars that undo the per-tensor quantisation scales (alpha *= *dq_a * *dq_w), or null
     unsigned short* aux;
+    float* colsum_part;       // optional [2 * nbm][N] partial column sums of a bf16 result (row epilogue of the 256-row kernel)
     unsigned char* f8_out; const float* f8_scale; float* f8_amax; int f8_e5m2;   // optional fp8 copy of a bf16 result (row epilogue of the 256-row kernel)
     int nbm, nbn;
     int group_m;              // >0: walk GROUP_M m-tiles per n-tile before moving on (L2-sized working set), 0: n fastest
@@ -212,7 +213,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 // residual and C are all accessed as whole contiguous row segments (64 columns = 256 B f32 / 128 B bf16, four rows per instruction).
 // lds_wave: >= 8704 bytes private to the calling wave, 16-byte aligned, not in use by anything else.
 template <int NJ, bool HASB, bool GELU, bool HASR, bool CBF, int AUXM>
-__device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int lane, unsigned char* lds_wave, int rows) {
+__device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int lane, unsigned char* lds_wave, int rows,
+                                                     int part_row) {
     static_assert(NJ % 2 == 0, "row epilogue works on pairs of 16-row blocks");
     constexpr int RS = 272;
     constexpr int NCH = NJ / 2;
@@ -233,6 +235,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
         const long long nld = n + 8 <= a.N ? n : (a.N >= 8 ? a.N - 8 : 0);        // a column group that lies inside the row (its values are unused when n is not whole)
         float f8max = 0.f;
         const float f8sc = a.f8_out && a.f8_scale ? *a.f8_scale : 1.f;
+        float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         uint4 ux[4];                               // this chunk's four side-tensor vectors; slot k is refilled for the next chunk right after its use
         auto load_aux = [&](const int ch, const int k) {
             long long m = mrow0 + ch * 32 + k * 8 + rr; if (m > a.M - 1) m = a.M - 1;
@@ -283,6 +286,11 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
                 uint4 o; pack(o);
                 if (whole) *reinterpret_cast<uint4*>(a.C + coff * 2) = o;
                 else *reinterpret_cast<uint2*>(a.C + coff * 2) = make_uint2(o.x, o.y);
+                if (a.colsum_part) {                // column sums of the bf16-rounded result (the bias gradient a colsum pass over C would give)
+                    const unsigned wc_[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { csum[2 * e] += __uint_as_float(wc_[e] << 16); csum[2 * e + 1] += __uint_as_float(wc_[e] & 0xffff0000u); }
+                }
                 if (a.f8_out && whole) {            // fp8 of the bf16-rounded values (what a stand-alone quantisation pass would read), saturating
                     const unsigned w8[4] = {o.x, o.y, o.z, o.w};
                     float qv[8];
@@ -303,6 +311,15 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
                     }
                     *reinterpret_cast<uint2*>(a.f8_out + m * a.N + n) = make_uint2((unsigned)q0, (unsigned)q1);
                 }
+            }
+        }
+        if (a.colsum_part) {                        // the 8 row groups of the wave (lane >> 3) hold the same 8 columns: add them up, lanes 0-7 store
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { csum[e] += __shfl_xor(csum[e], 8, 64); csum[e] += __shfl_xor(csum[e], 16, 64); csum[e] += __shfl_xor(csum[e], 32, 64); }
+            if (rr == 0 && whole) {
+                float* pr = a.colsum_part + (long long)part_row * a.N + n;
+                *reinterpret_cast<f32x4*>(pr) = (f32x4){csum[0], csum[1], csum[2], csum[3]};
+                *reinterpret_cast<f32x4*>(pr + 4) = (f32x4){csum[4], csum[5], csum[6], csum[7]};
             }
         }
         if (a.f8_out && a.f8_amax) {                // one guarded atomic per wave (non-negative floats order as their bit patterns)
@@ -378,16 +395,16 @@ __host__ __device__ inline bool rows_epilogue_applies(const GemmArgs& a) {
 }
 template <int NJ>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int lane, long long cshift,
-                                                   unsigned char* lds_wave, int rows = NJ * 16) {
+                                                   unsigned char* lds_wave, int rows = NJ * 16, int part_row = 0) {
     const int fr = lane & 15, fq = lane >> 4;
     if (cshift == 0 && (!a.R || a.r_dtype == OCC_F32)) {
         if (a.aux && !a.R && a.c_dtype != OCC_F32) {
-            if (a.act == OCC_ACT_GELU && a.bias) { gemm_epilogue_rows_t<NJ, true, true, false, true, 1>(a, acc, mrow0, ncol0, lane, lds_wave, rows); return; }
-            if (a.act == OCC_ACT_GELU_GRAD && !a.bias) { gemm_epilogue_rows_t<NJ, false, false, false, true, 2>(a, acc, mrow0, ncol0, lane, lds_wave, rows); return; }
+            if (a.act == OCC_ACT_GELU && a.bias) { gemm_epilogue_rows_t<NJ, true, true, false, true, 1>(a, acc, mrow0, ncol0, lane, lds_wave, rows, part_row); return; }
+            if (a.act == OCC_ACT_GELU_GRAD && !a.bias) { gemm_epilogue_rows_t<NJ, false, false, false, true, 2>(a, acc, mrow0, ncol0, lane, lds_wave, rows, part_row); return; }
         }
         if (!a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU)) {
             const int key = (a.bias ? 8 : 0) | (a.act == OCC_ACT_GELU ? 4 : 0) | (a.R ? 2 : 0) | (a.c_dtype != OCC_F32 ? 1 : 0);
-#define OCC_EPR(K, B, G, R, C) case K: gemm_epilogue_rows_t<NJ, B, G, R, C, 0>(a, acc, mrow0, ncol0, lane, lds_wave, rows); break;
+#define OCC_EPR(K, B, G, R, C) case K: gemm_epilogue_rows_t<NJ, B, G, R, C, 0>(a, acc, mrow0, ncol0, lane, lds_wave, rows, part_row); break;
             switch (key) {
                 OCC_EPR(0, false, false, false, false) OCC_EPR(1, false, false, false, true) OCC_EPR(2, false, false, true, false) OCC_EPR(3, false, false, true, true)
                 OCC_EPR(4, false, true, false, false) OCC_EPR(5, false, true, false, true) OCC_EPR(6, false, true, true, false) OCC_EPR(7, false, true, true, true)

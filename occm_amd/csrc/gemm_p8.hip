@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
     const unsigned long long dg_t2 = __builtin_amdgcn_s_memtime();
 #endif
     // all LDS is free here: no DMA is outstanding (the last phase waited vmcnt(0)) and every wave has finished its fragment reads
-    gemm_epilogue_rows<8>(a, acc, m0 + wr * (MB * 16), n0 + wc * 64, lane, 0, lds + wave * 16384, MB * 16);
+    gemm_epilogue_rows<8>(a, acc, m0 + wr * (MB * 16), n0 + wc * 64, lane, 0, lds + wave * 16384, MB * 16, tile_m * 2 + wr);
 #ifdef P8_DIAG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {

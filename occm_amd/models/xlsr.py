@@ -590,10 +590,12 @@ class XlsrFineTuner(XlsrFrontend):
             self._f8_pre = (4, kn, 1 - slot)
         ops.gemm_raw(M, N, K, q, rowmap(M, 0, K), self.f8["wq"][name], K, C, c_map, c_dtype, self.f8["e4"], a_dequant=inv_a, w_dequant=self.f8["inv4"][kw_:kw_ + 1], **kw)
 
-    def _dgrad(self, i, wn, dy, gsite, M, N, K, C, f8_next=None, **kw):
+    def _dgrad(self, i, wn, dy, gsite, M, N, K, C, f8_next=None, colsum=None, **kw):
         """Input gradient dX [M,N] = dY [M,K] . W (through W^T [N,K]) of layer i's weight wn.  f8_next: the gradient site whose e5m2 operand
         is this GEMM's bf16 result (as in _lin)."""
         name = "l%d.%s" % (i, wn)
+        if colsum is not None:                                   # (the caller has checked that this launch takes the 256-row kernel)
+            kw["c_colsum"] = colsum
         if not getattr(self, "fp8", False):
             ops.gemm_raw(M, N, K, dy, rowmap(M, 0, K), self.wT[name], K, C, rowmap(M, 0, N), OCC_BF16_CODE, OCC_BF16_CODE, **kw)
             return
@@ -844,12 +846,15 @@ class XlsrFineTuner(XlsrFrontend):
             dyb = dxb
             if p_res > 0:
                 dyb = tr["dyb"]; self._drop_bwd("l%d.d3" % i, dxb, dyb, p_res)
-            self._dgrad(i, "fc2.w", dyb, "g_fc2", M, Fd, D, tr["du"], act=ACT_GELU_GRAD, aux=s["u"], f8_next="g_fc1" if p_act == 0 else None)
+            # fc1's bias gradient = column sums of du: from the same epilogue that writes du (large launches, no activation dropout on du)
+            fc1_bias_fused = p_act == 0 and M * Fd >= 180 * 65536 and Fd % 8 == 0 and D % 64 == 0
+            self._dgrad(i, "fc2.w", dyb, "g_fc2", M, Fd, D, tr["du"], act=ACT_GELU_GRAD, aux=s["u"], f8_next="g_fc1" if p_act == 0 else None,
+                        colsum=self.mg["l%d.fc1.b" % i] if fc1_bias_fused else None)
             if p_act > 0:                                        # (elementwise factors commute: mask after GELU')
                 self._drop_bwd("l%d.act" % i, tr["du"], tr["du"], p_act)
             # both FFN weight gradients in one launch (dyb is not rewritten before the LayerNorm backward below)
             self._wgrad_pair(M, (dyb, s["f"], D, Fd, "l%d.fc2.w" % i, None if fc2_bias_done.get(i) else "l%d.fc2.b" % i),
-                             (tr["du"], s["h2"], Fd, D, "l%d.fc1.w" % i, "l%d.fc1.b" % i))
+                             (tr["du"], s["h2"], Fd, D, "l%d.fc1.w" % i, None if fc1_bias_fused else "l%d.fc1.b" % i))
             self._dgrad(i, "fc1.w", tr["du"], "g_fc1", M, D, Fd, tr["dh"])
             o_bias_done = self._ln_bwd(tr["dh"], s["x_mid"], "l%d.ln2" % i, dx, dx, dxb, bias_name="l%d.o.b" % i if fuse else None,
                                        f8_site=i * 4 + self._E5["g_o"] if fuse else None)
@@ -858,12 +863,16 @@ class XlsrFineTuner(XlsrFrontend):
             if p_res > 0:
                 dyb = tr["dyb"]; self._drop_bwd("l%d.d1" % i, dxb, dyb, p_res)
             self._dgrad(i, "o.w", dyb, "g_o", M, D, D, tr["da"])
+            qkv_bias_done = False
             if p_att > 0:
                 ops.attention_bwd_dropout(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, self.masks["l%d.att" % i], p_att, dqkv=tr["dqkv"])
+            elif T <= 256:                                       # one key block: the kernel that writes dqkv also sums its columns (the qkv bias gradient)
+                ops.attention_bwd_bias(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, self.mg["l%d.qkv.b" % i], dqkv=tr["dqkv"])
+                qkv_bias_done = True
             else:
                 ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
             self._wgrad_pair(M, (dyb, s["att"], D, D, "l%d.o.w" % i, None if o_bias_done else "l%d.o.b" % i),
-                             (tr["dqkv"], s["h1"], 3 * D, D, "l%d.qkv.w" % i, "l%d.qkv.b" % i))
+                             (tr["dqkv"], s["h1"], 3 * D, D, "l%d.qkv.w" % i, None if qkv_bias_done else "l%d.qkv.b" % i))
             self._dgrad(i, "qkv.w", tr["dqkv"], "g_qkv", M, D, 3 * D, tr["dh"])
             j = below(i)
             done = self._ln_bwd(tr["dh"], s["x_in"], "l%d.ln1" % i, dx, dx, dxb, bias_name="l%d.fc2.b" % j if fuse and j is not None else None,

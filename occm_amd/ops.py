@@ -28,7 +28,7 @@ def rowmap(rows_per_batch, batch_stride, row_stride, rows_per_line=0, line_strid
 
 
 def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, act=ACT_NONE, alpha=1.0,
-             R=None, r_map=None, r_dtype=OCC_F32, a_seg=None, groups=None, aux=None, a_dequant=None, w_dequant=None, c_f8=None):
+             R=None, r_map=None, r_dtype=OCC_F32, a_seg=None, groups=None, aux=None, a_dequant=None, w_dequant=None, c_f8=None, c_colsum=None):
     """Direct descriptor-level call.  A/W/C/R/bias are ints (device addresses) or tensors."""
     d = GemmDesc()
     d.M, d.N, d.K = int(M), int(N), int(K)
@@ -61,6 +61,9 @@ def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, 
         d.w_dequant = w_dequant if isinstance(w_dequant, int) else w_dequant.data_ptr()
     if c_f8 is not None:                       # (u8 buffer, scale scalar, amax scalar, fp8 format): fp8 copy of the bf16 result from the same epilogue
         d.c_f8, d.c_f8_scale, d.c_f8_amax, d.c_f8_fmt = c_f8[0].data_ptr(), c_f8[1].data_ptr(), c_f8[2].data_ptr(), int(c_f8[3])
+    if c_colsum is not None:                   # f32 [N] += column sums of the bf16 result (bias gradient), from the same epilogue
+        ws = small_scratch()
+        d.c_colsum, d.c_colsum_ws, d.c_colsum_ws_floats = c_colsum.data_ptr(), ws.data_ptr(), ws.numel()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -127,6 +130,17 @@ def attention_bwd(qkv, o, dout, lse, B, T, H, hd, scale, dqkv=None):
     acc = torch.empty(B * T, D, device=qkv.device, dtype=torch.float32) if T > 256 else None      # the key blocks of a head meet here
     check(lib().occ_attention_bwd(ptr(qkv), ptr(o), ptr(dout), ptr(lse), ptr(dqkv), B, T, H, hd, 3 * D, D, float(scale), ptr(acc), stream_ptr()),
           "occ_attention_bwd")
+    return dqkv
+
+
+def attention_bwd_bias(qkv, o, dout, lse, B, T, H, hd, scale, dbias, dqkv=None):
+    """attention_bwd (T <= 256) that also adds the column sums of dqkv -- the q|k|v bias gradient -- into dbias f32 [3D]."""
+    D = H * hd
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    ws = small_scratch()
+    check(lib().occ_attention_bwd_bias(ptr(qkv), ptr(o), ptr(dout), ptr(lse), ptr(dqkv), B, T, H, hd, 3 * D, D, float(scale), ptr(dbias), ptr(ws), ws.numel(),
+                                       stream_ptr()), "occ_attention_bwd_bias")
     return dqkv
 
 

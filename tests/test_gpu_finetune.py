@@ -119,6 +119,11 @@ def test_attention_fwd_lse_and_bwd(B, T, H, hd):
     ref_lse = torch.logsumexp(s.detach(), -1).reshape(B * H, T) * 1.4426950408889634
     torch.testing.assert_close(lse.cpu(), ref_lse, rtol=1e-3, atol=2e-3)
     dqkv = ops.attention_bwd(qkv.cuda(), out, do.cuda(), lse, B, T, H, hd, hd ** -0.5)
+    if T <= 256:            # the form that also sums the columns of dqkv (the q|k|v bias gradient): same dqkv, sums = those of the bf16 tensor
+        db = torch.full((3 * H * hd,), 0.125, device="cuda")
+        dqkv2 = ops.attention_bwd_bias(qkv.cuda(), out, do.cuda(), lse, B, T, H, hd, hd ** -0.5, db)
+        assert torch.equal(dqkv2, dqkv)
+        torch.testing.assert_close(db.cpu(), 0.125 + dqkv.float().sum(0).cpu(), rtol=1e-4, atol=1e-3 * max(1.0, float(dqkv.float().abs().sum(0).max())))
     for j, n in enumerate("qkv"):
         _close(dqkv[:, j * D:(j + 1) * D], x.grad[:, j * D:(j + 1) * D], cos_min=0.998, rel=4e-2, name="d" + n)
 

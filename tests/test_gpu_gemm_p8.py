@@ -172,3 +172,28 @@ def test_p8_race_screen_bitwise_repeatable():
                 torch.testing.assert_close(out, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
             else:
                 assert torch.equal(out, first[i]), (it, M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(12736, 4096, 1024), (6368, 5120, 1280), (12100, 1024, 512)])
+def test_gelu_grad_epilogue_also_gives_the_column_sums(M, N, K):
+    """occ_gemm c_colsum: the bias gradient of fc1 (column sums of du = dY.W2 * GELU'(u)) from the epilogue that writes du, against
+    occ_colsum over the bf16 result; accumulates onto what the buffer holds, twice gives twice (fixed summation order: bit-equal runs)."""
+    from occm_amd import backend_ops as K_, ops
+    from occm_amd._lib import ACT_GELU_GRAD, OCC_BF16
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda(); w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+    u = torch.randn(M, N, generator=g).bfloat16().cuda()
+    C0, C1 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    run = lambda C, **kw: ops.gemm_raw(M, N, K, x, ops.rowmap(M, 0, K), w, K, C, ops.rowmap(M, 0, N), OCC_BF16, OCC_BF16, act=ACT_GELU_GRAD, aux=u, **kw)
+    run(C0)
+    ref = torch.full((N,), 0.5, device="cuda")
+    K_.colsum(C0, ops.rowmap(M, 0, N), M, N, ref)
+    cs = torch.full((N,), 0.5, device="cuda")
+    run(C1, c_colsum=cs)
+    assert torch.equal(C1, C0)
+    torch.testing.assert_close(cs, ref, rtol=1e-4, atol=1e-2)
+    exact = 0.5 + C0.double().sum(0).float()
+    torch.testing.assert_close(cs, exact, rtol=1e-4, atol=1e-2)
+    cs2 = torch.full((N,), 0.5, device="cuda")
+    run(C1, c_colsum=cs2)
+    assert torch.equal(cs2, cs)
