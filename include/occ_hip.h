@@ -72,6 +72,21 @@ int occ_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n
 /* Counter-based N(0,1) / U[0,1) fill (Philox4x32-10), element i uses counter (i/4, stream_id).   */
 int occ_philox_fill(void* dst, int dtype, int64_t n, uint64_t seed, uint64_t stream_id, int normal, void* stream);
 
+/* Fused attention core of the graph layers (GraphAttentionLayer sslassist.py:102-130, HtrgGraphAttentionLayer :271-300), bf16 MFMA
+ * with f32 accumulate -- replaces occ_pair_mul + occ_gemm(att_proj, tanh) + occ_gat_softmax + occ_bmm_alpha and their [B,N,N,D] /
+ * [B,N,N,Do] tensors:  alpha[b,i,:] = softmax_j(aw_type(i,j) . tanh(W (x_i o x_j) + b) * inv_temp),  h[b,i,:] = sum_j alpha[b,i,j] x[b,j,:].
+ * x f32 [B,N,D]; att_w f32 [Do,D]; att_b [Do]; aw3 f32 [3,Do] = (w11, w22, w12) with type by (i < n1, j < n1), n1 = N for homogeneous
+ * layers; alpha f32 [B,N,N] and h f32 [B,N,D] out.  (D, Do) in {(64,64), (64,32), (32,32)}.                                       */
+int occ_gat_core_fwd(const float* x, const float* att_w, const float* att_b, const float* aw3, float* alpha, float* h, int64_t B, int64_t N,
+                     int64_t D, int64_t Do, int64_t n1, float inv_temp, void* stream);
+/* Its backward through the score path, given ds = d loss / d score f32 [B,N,N] (occ_gat_dscore): z is recomputed, nothing of size
+ * N*N*D is stored.  dx f32 [B,N,D] += gradient through the pairwise products (add the alpha^T dh term with occ_bmm_alpha);
+ * d_att_w [Do,D], d_att_b [Do], d_aw3 [3,Do] are accumulated from per-workgroup records in a fixed order (reproducible); ws: f32
+ * scratch of at least B * ceil(N / 16) * (Do*D + 4*Do) floats, 16-byte aligned.  N such that the kernel's LDS image fits (N <= 96 for
+ * (64,64)); OCC_EINVAL otherwise.                                                                                                */
+int occ_gat_core_bwd(const float* x, const float* att_w, const float* att_b, const float* aw3, const float* ds, float* dx, float* d_att_w,
+                     float* d_att_b, float* d_aw3, int64_t B, int64_t N, int64_t D, int64_t Do, int64_t n1, float* ws, int64_t ws_floats,
+                     void* stream);
 /* ---------------------------------------------------- losses (losses/custom_loss.py) ------ */
 /* compactness_loss (custom_loss.py:4-29) over groups of `group` rows: rows [g*group, g*group+6) of
  * emb f32 [n_groups*group, E]; loss[0] = mean over groups of the reference's 6-row value.

@@ -204,6 +204,23 @@ def gat_dscore(alpha, dh, x, ds, B, N, D, inv_temp):
     check(lib().occ_gat_dscore(_a(alpha), _a(dh), _a(x), _a(ds), B, N, D, float(inv_temp), stream_ptr()), "occ_gat_dscore")
 
 
+def gat_core_fwd(x, att_w, att_b, aw3, alpha, h, B, N, D, Do, n1, inv_temp):
+    check(lib().occ_gat_core_fwd(_a(x), _a(att_w), _a(att_b), _a(aw3), _a(alpha), _a(h), B, N, D, Do, n1, float(inv_temp), stream_ptr()), "occ_gat_core_fwd")
+
+
+_GAT_WS = {}
+
+
+def gat_core_bwd(x, att_w, att_b, aw3, ds, dx, d_att_w, d_att_b, d_aw3, B, N, D, Do, n1):
+    need = B * ((N + 15) // 16) * (Do * D + 4 * Do)
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    ws = _GAT_WS.get(key)
+    if ws is None or ws.numel() < need:                        # per-workgroup weight-gradient records (summed in order by a second launch)
+        ws = _GAT_WS[key] = torch.empty(need, device="cuda", dtype=torch.float32)
+    check(lib().occ_gat_core_bwd(_a(x), _a(att_w), _a(att_b), _a(aw3), _a(ds), _a(dx), _a(d_att_w), _a(d_att_b), _a(d_aw3), B, N, D, Do, n1, _a(ws), ws.numel(),
+                                 stream_ptr()), "occ_gat_core_bwd")
+
+
 def gat_dz(A, ds, aw, B, N, Do, n1, daw):
     check(lib().occ_gat_dz(_a(A), _a(ds), _a(aw), B, N, Do, n1, _a(daw), stream_ptr()), "occ_gat_dz")
 

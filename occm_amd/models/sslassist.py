@@ -102,6 +102,8 @@ class AasistBackend:
         if compute not in ("f32", "bf16"):
             raise OccError("compute must be 'f32' or 'bf16'")
         self.compute = compute
+        import os
+        self.fuse_gat = os.environ.get("OCC_GAT_FUSED", "1") != "0"
         # weight gradients: exact-f32 MFMA on the parity path, bf16 MFMA (f32 accumulate) in bf16 compute mode
         self._tn = functools.partial(K.gemm_tn, bf16_mfma=(compute == "bf16"))
         self.device = torch.device(device)
@@ -417,6 +419,11 @@ class AasistBackend:
     # ---- GraphAttentionLayer (sslassist.py:58-151) ------------------------------------------------
     def _att_core_fwd(self, pre, xd, B, N, D, Do, n1, c):
         """pairwise product -> att_proj+tanh -> typed score -> softmax -> alpha@x."""
+        if self._fused_gat(N, D, Do):         # bf16-compute mode: one kernel, no [B,N,N,D] / [B,N,N,Do] tensors (csrc/gat_fused.hip)
+            alpha, h = self._e(B, N, N), self._e(B, N, D)
+            K.gat_core_fwd(xd, self.p[pre + ".att_proj.weight"], self.p[pre + ".att_proj.bias"], self.p[pre + ".aw3"], alpha, h, B, N, D, Do, n1, 1.0 / TEMPS[pre])
+            c[pre + ".P"], c[pre + ".A"], c[pre + ".alpha"], c[pre + ".h"] = None, None, alpha, h
+            return h
         P = self._e(B * N * N, D)
         K.pair_mul(xd, P, B, N, D)
         A = self._lin(P, B * N * N, D, pre + ".att_proj", Do, act=ACT_TANH)
@@ -426,6 +433,11 @@ class AasistBackend:
         K.bmm_alpha(alpha, xd, h, B, N, D, 0, 0)
         c[pre + ".P"], c[pre + ".A"], c[pre + ".alpha"], c[pre + ".h"] = P, A, alpha, h
         return h
+
+    def _fused_gat(self, N, D, Do):
+        """The fused attention-core kernels: bf16-compute mode (the exact-f32 parity mode keeps the unfused f32 path), the AASIST layer
+        widths, node counts whose backward LDS image fits (N <= 96: 4 s utterances give 42 / 66 / 54 / 26)."""
+        return self.compute == "bf16" and self.fuse_gat and (D, Do) in ((64, 64), (64, 32), (32, 32)) and N <= 96
 
     def _gat_fwd(self, pre, x, B, N, c, train, masks):
         D = Do = 64
@@ -447,6 +459,10 @@ class AasistBackend:
         K.bmm_alpha(alpha, dh, dxd, B, N, D, 1, 1)
         ds = self._e(B, N, N)
         K.gat_dscore(alpha, dh, xd, ds, B, N, D, 1.0 / TEMPS[pre])
+        if P is None:                          # fused forward: z is recomputed in the fused backward, nothing of size N*N*D was kept
+            K.gat_core_bwd(xd, self.p[pre + ".att_proj.weight"], self.p[pre + ".att_proj.bias"], self.p[pre + ".aw3"], ds, dxd, self.g[pre + ".att_proj.weight"],
+                           self.g[pre + ".att_proj.bias"], self.g[pre + ".aw3"], B, N, D, Do, n1)
+            return
         K.gat_dz(A, ds, self.p[pre + ".aw3"], B, N, Do, n1, self.g[pre + ".aw3"])          # A <- dZ
         M = B * N * N
         dP = self._lin_bwd(A, rowmap(M, 0, Do), P, rowmap(M, 0, D), M, D, pre + ".att_proj", Do)

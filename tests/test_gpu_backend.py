@@ -530,3 +530,48 @@ def test_gemm_tn_fuzz(seed):
         assert float((C.cpu().double() - ref).abs().max()) <= tol, (kind, M, N1, N2, nseg, float((C.cpu().double() - ref).abs().max()), tol)
         sref = alpha * torch.stack(ar_src).double().sum(0)          # the bias gradient sums the operand as stored (un-rounded f32, or the bf16 values)
         torch.testing.assert_close(cs.cpu().double(), sref, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("pre,N,D,Do,n1", [("GAT_layer_T", 66, 64, 64, 66), ("GAT_layer_S", 42, 64, 64, 42), ("HtrgGAT_layer_ST11", 54, 64, 32, 33),
+                                           ("HtrgGAT_layer_ST12", 26, 32, 32, 16), ("GAT_layer_T", 93, 64, 64, 93), ("HtrgGAT_layer_ST21", 7, 64, 32, 4)])
+def test_fused_graph_attention_core_matches_the_unfused_kernels_and_f64(pre, N, D, Do, n1):
+    """csrc/gat_fused.hip (one kernel forward, one backward, no [B,N,N,D] tensors) against (a) the unfused kernel chain it replaces in
+    the bf16-compute mode and (b) an f64 torch evaluation of sslassist.py:102-130 / 271-300 with autograd: attention map, aggregated
+    features, and the gradients wrt the node features, att_proj and the (typed) attention weights.  Both device paths round the same
+    operands to bf16, so they must sit equally close to the f64 values."""
+    from occm_amd.models.sslassist import AasistBackend, TEMPS
+    B = 5
+    g = torch.Generator().manual_seed(N + D)
+    xd = torch.randn(B, N, D, generator=g)
+    dh = torch.randn(B, N, D, generator=g)
+    res = {}
+    for fused in (False, True):
+        be = AasistBackend(device="cuda", seed=0, compute="bf16")
+        be.fuse_gat = fused
+        be.zero_grad()
+        c = {pre + ".xd": xd.cuda()}
+        h = be._att_core_fwd(pre, c[pre + ".xd"], B, N, D, Do, n1, c)
+        assert (c[pre + ".P"] is None) == fused
+        dxd = torch.full((B, N, D), 0.5, device="cuda")
+        be._att_core_bwd(pre, dh.cuda(), dxd, B, N, D, Do, n1, c)
+        res[fused] = dict(alpha=c[pre + ".alpha"].cpu().double(), h=h.cpu().double(), dxd=dxd.cpu().double() - 0.5, gW=be.g[pre + ".att_proj.weight"].cpu().double(),
+                          gb=be.g[pre + ".att_proj.bias"].cpu().double(), gaw=be.g[pre + ".aw3"].cpu().double())
+        W, bb, aw3 = be.p[pre + ".att_proj.weight"].cpu().double(), be.p[pre + ".att_proj.bias"].cpu().double(), be.p[pre + ".aw3"].cpu().double()
+    # f64 reference
+    x = xd.double().requires_grad_(True)
+    W_, b_, aw_ = W.clone().requires_grad_(True), bb.clone().requires_grad_(True), aw3.clone().requires_grad_(True)
+    z = torch.tanh(torch.einsum("bijd,od->bijo", x.unsqueeze(2) * x.unsqueeze(1), W_) + b_)
+    idx = torch.arange(N)
+    ty = torch.where(idx[:, None] < n1, torch.where(idx[None, :] < n1, 0, 2), torch.where(idx[None, :] < n1, 2, 1))
+    score = (z * aw_[ty]).sum(-1) / TEMPS[pre]
+    alpha = torch.softmax(score, dim=-1)
+    h = alpha @ x
+    (h * dh.double()).sum().backward()
+    ref = dict(alpha=alpha.detach(), h=h.detach(), dxd=x.grad, gW=W_.grad, gb=b_.grad, gaw=aw_.grad)
+    for k in ref:
+        scale = float(ref[k].abs().max()) + 1e-12
+        e_un, e_fu = float((res[False][k] - ref[k]).abs().max()) / scale, float((res[True][k] - ref[k]).abs().max()) / scale
+        assert e_fu < max(2.5e-2, 2.0 * e_un), (k, e_fu, e_un)
+        assert float((res[True][k] - res[False][k]).abs().max()) / scale < 4e-2, k
+    if n1 == N:
+        assert float(res[True]["gaw"][1:].abs().max()) == 0.0            # homogeneous layers touch w11 only
