@@ -47,6 +47,7 @@ def parse_args(argv=None):
                     "delayed per-tensor scaling), as BASELINE configs[4] asks for XLS-R-1B; weight gradients stay bf16")
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the XLS-R gradients on the xGMI links (bf16 halves the 1.26 GB "
                     "payload; sums are widened back into the f32 gradient buffer before Adam).  Default f32 = the exact sum")
+    ap.add_argument("--print-workload", action="store_true", help="print the workload tag of these flags (what scripts/pmc_summary.py stores in a PMC profile) and exit")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous only (gloo, no GPU call): every rank reports world size and its shard of the "
                     "utterance groups, rank 0 prints them as one JSON line")
     return ap.parse_args(argv)
@@ -242,20 +243,28 @@ def gemm_source_sha():
     return h.hexdigest()[:16]
 
 
+def workload_tag(args, finetune, bs, rawboost):
+    """Identifies the measured workload (model, back-end, batch, dtype, augmentation): a PMC profile is quoted only for its own workload."""
+    return "xlsr-%s/%s/%s/bs%d/rawboost%d/%s" % (args.xlsr, args.backend, ("finetune-" + str(finetune)) if finetune else "frozen", bs, rawboost, "fp8" if args.fp8 else "bf16")
+
+
 def pmc_traffic(tag):
-    """HBM bytes per GEMM launch from the committed PMC passes of THIS workload -- reported only when the profile was taken with the
-    GEMM sources of this tree (their hash is stored in the profile), otherwise null: a stale counter must not look like a measurement."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_%s.json" % tag)
-    try:
-        pm = json.load(open(path))
-        if pm.get("gemm_src_sha16") != gemm_source_sha():
-            return None, "profiles/%s is from other GEMM sources (%s): not reported" % (os.path.basename(path), pm.get("gemm_src_sha16"))
-        ks = [v for k, v in pm["kernels"].items() if ("gemm_" in k and "bf16" in k) or "gemm_p8_kernel<0" in k or "gemm_tn_p8" in k or "gemm_tn_dma" in k]      # (bf16 forms; not the slab reduce kernels)
-        n = sum(v["launches"] for v in ks)
-        return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks) / max(n, 1)), \
-            "profiles/%s (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE, launch-weighted over the bf16 GEMM kernels)" % os.path.basename(path)
-    except (OSError, KeyError, ValueError):
-        return None, None
+    """HBM bytes per GEMM launch from the committed PMC passes -- reported only when a profile of THIS workload (its tag is stored in the
+    profile) taken with the GEMM sources of this tree (their hash is stored too) exists under profiles/; otherwise null: a counter from
+    another model, dtype, batch or build must not look like a measurement of this run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_*.json")), reverse=True):
+        try:
+            pm = json.load(open(path))
+            if pm.get("workload") != tag or pm.get("gemm_src_sha16") != gemm_source_sha():
+                continue
+            ks = [v for k, v in pm["kernels"].items() if ("gemm_" in k and "bf16" in k) or "gemm_p8_kernel" in k or "gemm_tn_p8" in k or "gemm_tn_dma" in k]      # (GEMM kernels; not the slab reduce)
+            n = sum(v["launches"] for v in ks)
+            return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks) / max(n, 1)), \
+                "profiles/%s (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE, launch-weighted over the GEMM kernels)" % os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, "no PMC profile of this workload (%s) with these GEMM sources under profiles/" % tag
 
 
 # ------------------------------------------------------------------------------------------------- main
@@ -265,6 +274,11 @@ def main():
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.dry_launch:
         sys.exit(dry_launch(args))
+    if args.print_workload:
+        ft = False if args.frozen else (args.finetune or "full")
+        print(workload_tag(args, ft, args.bs if args.bs is not None else (BS_FROZEN if args.frozen else BS_FINETUNE),
+                           args.rawboost if args.rawboost is not None else (0 if args.frozen else 5)))
+        sys.exit(0)
 
     import torch
     from occm_amd import backend_ops, ops, parallel
@@ -364,7 +378,7 @@ def main():
             Ts = conv_frames(L_SAMPLES)
             fl = gemm_flops_per_utt(cfg, L_SAMPLES) * bs + 2 * (2 * Ts[-1] * (4 * cfg.dim ** 2 + 2 * cfg.dim * cfg.ffn) * cfg.layers) * bs
         ach = fl / (t_ms * 1e-3) / 1e12
-        traffic, tnote = pmc_traffic("frozen" if not finetune else "finetune")
+        traffic, tnote = pmc_traffic(workload_tag(args, finetune, bs, rawboost))
         peak = 5000.0 if args.fp8 else BF16_DENSE_PEAK_TFLOPS       # (~5 PF dense fp8; the bf16 weight-gradient launches are priced against it too)
         roof = {"kernel": ("fp8 + " if args.fp8 else "") + "bf16 MFMA GEMM family: every Linear / Conv1d launch of the XLS-R front-end" +
                 (" -- forward, input gradient (occ_gemm) and weight gradient (occ_gemm_tn)" if finetune else " (occ_gemm)"),

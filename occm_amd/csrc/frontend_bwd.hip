@@ -675,7 +675,15 @@ __global__ __launch_bounds__(256) void wn_norms_kernel(const float* __restrict__
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
     float t = 0.f;
-    for (int j = 0; j < S; ++j) t += partial[(long long)j * K + k];
+    int j = 0;
+    for (; j + 32 <= S; j += 32) {                  // 32 independent loads in flight, added in row order (one latency per 32 rows, not per row)
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = partial[(long long)(j + u) * K + k];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) t += v[u];
+    }
+    for (; j < S; ++j) t += partial[(long long)j * K + k];
     norms[k] = sqrtf(t);
 }
 __global__ __launch_bounds__(256) void wn_pack_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ norms,

@@ -1,5 +1,5 @@
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (two separate runs, CSV output) -> profiles/rNN_pmc_hbm.json.
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [workload tag printed by `bench.py --print-workload`]
 HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE reports half of a wide coalesced read
 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte-per-lane stores."""
 import collections, csv, json, re, sys
@@ -32,5 +32,8 @@ for _n in ("gemm.hip", "gemm_common.h", "gemm_tn.hip", "gemm_p8.hip", "gemm_tn_p
     if os.path.exists(_p):
         _h.update(open(_p, "rb").read())
 out["gemm_src_sha16"] = _h.hexdigest()[:16]
+# the workload the counters were taken on (bench.py's config.workload string + dtype): bench.py reports `traffic` only for that workload
+if len(sys.argv) > 4:
+    out["workload"] = sys.argv[4]
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print("wrote", sys.argv[3], len(out["kernels"]), "kernels")

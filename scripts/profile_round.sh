@@ -15,7 +15,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $ROOT/gpurun_out/prof_write -o
 rocprofv3 --pmc MfmaUtil GRBM_GUI_ACTIVE --output-format csv -d $ROOT/gpurun_out/prof_mfma -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $ROOT/gpurun_out/prof_mfma.err
 cd $ROOT
 python3 scripts/pmc_mfma_summary.py gpurun_out/prof_mfma/bench_counter_collection.csv gpurun_out/${TAG}_pmc_mfma.json
-python3 scripts/pmc_summary.py gpurun_out/prof_fetch/bench_counter_collection.csv gpurun_out/prof_write/bench_counter_collection.csv gpurun_out/${TAG}_pmc_hbm_finetune.json
+python3 scripts/pmc_summary.py gpurun_out/prof_fetch/bench_counter_collection.csv gpurun_out/prof_write/bench_counter_collection.csv gpurun_out/${TAG}_pmc_hbm_finetune.json "$(python3 bench.py --print-workload)"
 rm -rf gpurun_out/prof_mfma gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_stats
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 cat gpurun_out/${TAG}_bench.json
