@@ -13,12 +13,17 @@ class OcTrainer:
     0.0 / 1.0 (oc_training.py:380-381); the SE-ResNet script uses 0.1 / 0.9 (test_dataloader_v2.py:127)."""
 
     def __init__(self, model, lr=1e-5, w_compact=0.0, w_descr=1.0, train_frontend=False, group_size=None, dropout_masks=None, rawboost_algo=0,
-                 rawboost_args=None, seed=0, rank=0, graph_backend=True, grad_wire_dtype=None):
+                 rawboost_args=None, seed=0, rank=0, graph_backend=True, grad_wire_dtype=None, graph_frontend=None):
         """graph_backend: replay the back-end section of a step (zero_grad, forward, losses, backward: ~560 small launches for AASIST) from a
         HIP graph once a batch shape has come twice in a row (fixed-length training); until then, and for every other shape, steps run eagerly.  Needs device-drawn dropout masks
         (``dropout_masks=None``): injected masks run eagerly."""
         self.model = model
         self.graph_backend = graph_backend
+        import os as _os
+        # off unless asked for (graph_frontend=True / OCC_FE_GRAPH=1): measured on one MI355X the replayed front-end is no faster than eager
+        # launches (configs[2] 50.62 vs 50.38 ms per step, configs[4]'s shard 86.66 vs 86.39): the step is GPU-bound, see _step_finetune
+        self.graph_frontend = (_os.environ.get("OCC_FE_GRAPH", "0") == "1") if graph_frontend is None else bool(graph_frontend)
+        self._fe_graphs, self._fe_last_key = {}, None
         self._graphs, self._last_key = {}, None
         # every data-parallel rank draws its own augmentation parameters: the rank is part of the RawBoost seed
         self.rawboost_algo, self.rawboost_args, self.seed, self.nstep = rawboost_algo, rawboost_args, seed * 4096 + rank, 0
@@ -200,7 +205,84 @@ class OcTrainer:
         aug.record_stream(main)                            # allocated on the side stream, consumed on the main one
         self._pref_aug = (next_wav, aug, ready)
 
+    def _frontend_graphable(self):
+        """The fine-tuning front-end can be replayed from HIP graphs when nothing in it depends on per-step host decisions: one rank (the
+        per-layer all-reduce hooks are host callbacks), no active fairseq dropout / layerdrop (their Philox stream ids and keep decisions
+        are host values), fp8 scales past their first (measuring) step, no per-launch profiling."""
+        fe = self.fe
+        if not self.graph_frontend or ops.PROFILE is not None or self.overlap_optimizer or any(r.world > 1 for r in self.reducers):
+            return False
+        tc = getattr(fe, "train_cfg", None)
+        if tc is not None and getattr(fe, "dropout_active", True) and tc.any_dropout():
+            return False
+        if getattr(fe, "fp8", False) and fe.f8["warm"]:
+            return False
+        return getattr(fe, "inject_masks", None) is None and getattr(fe, "inject_keep", None) is None
+
     def _step_finetune(self, wav, labels, next_wav=None, next_step=0):
+        """Fine-tuning step.  A step enqueues ~1300 launches (2500 for XLS-R-1B) through ctypes: measured 46.6 ms of host time per step
+        against 50.6 ms of wall time at configs[2], 79.9 against 87.1 ms on configs[4]'s shard -- close enough to host-bound to check.  With
+        graph_frontend the front-end forward and {front-end backward, Adam, operand refresh} are each replayed from a HIP graph once a batch
+        shape has come twice in a row (as the back-end section is); the glue between them (the gradient clear on the side stream, RawBoost
+        of the next batch, the back-end section's own graph) stays eager.  Same kernels, same order, same arithmetic -- and, measured, the
+        same step time: the host runs ahead of the GPU either way, so this stays an option (it frees the host for the data loader)."""
+        fe = self.fe
+        key = (tuple(wav.shape), bool(getattr(fe, "fp8", False)))
+        ok = self._frontend_graphable()
+        rec = self._fe_graphs.get(key) if ok else None
+        if rec is not None and rec.get("fwd") is not None:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=wav.device)
+            rec["wav"].copy_(wav)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                fe.zero_grad()
+                cleared = torch.cuda.Event()
+                cleared.record(self._side)
+            rec["fwd"].replay()
+            if next_wav is not None:
+                self._prefetch_augment(next_wav, next_step)
+            main.wait_event(cleared)
+            lc, ld, dfeats = self._backend_section(rec["feats"], labels, True)
+            rec["dfeats"].copy_(dfeats.view_as(rec["dfeats"]))
+            rec["bwd"].replay()
+            self._fe_last_key = key
+            self.last = (lc, ld)
+            return lc, ld
+        out = self._step_finetune_eager(wav, labels, next_wav, next_step)
+        repeat = ok and self._fe_last_key == key
+        self._fe_last_key = key if ok else None
+        if repeat and self._frontend_graphable():               # (fp8: the step just taken may have been the measuring one)
+            try:
+                self._capture_frontend(key, wav)
+            except Exception as e:                              # capture is an optimisation: never let it break training
+                self._fe_graphs.pop(key, None)
+                self.graph_frontend = False
+                import warnings
+                warnings.warn("occm_amd: front-end HIP-graph capture failed (%s); continuing with eager launches" % (e,))
+        return out
+
+    def _capture_frontend(self, key, wav):
+        fe = self.fe
+        rec = {"wav": wav.clone()}
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+            rec["feats"] = fe.forward_train(rec["wav"])
+        rec["dfeats"] = torch.zeros_like(rec["feats"])
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+            fe.backward(rec["dfeats"])
+            self.opt.step(self._grads, grad_scale=self.reducer.grad_scale)
+            fe.refresh_operands(cast=not hasattr(fe, "Wb"))
+        self.opt.step_count -= 1                                 # capturing enqueued nothing: the host-side step counter counts executed steps
+        rec["fwd"], rec["bwd"] = g1, g2
+        self._fe_graphs[key] = rec
+        while len(self._fe_graphs) > 2:
+            self._fe_graphs.pop(next(iter(self._fe_graphs)))
+
+    def _step_finetune_eager(self, wav, labels, next_wav=None, next_step=0):
         be, fe = self.be, self.fe
         # the front-end's gradient buffer (1.26 GB) is cleared on the side stream while the forward pass runs: nothing reads it before
         # the backward pass, and the previous step's optimizer (its last reader) is already enqueued on the main stream

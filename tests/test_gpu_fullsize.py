@@ -132,8 +132,9 @@ def test_finetune_300m_step_gradients_match_oracle_autograd_and_bs64_is_linear(o
         backward: isolates 24 layers of bf16 forward + backward -- measured cosine >= 0.9999, max error <= 1.6 % of the tensor's largest
         entry (a tensor whose whole gradient is ~1e-3 of the typical one sits at bf16 noise level and is bounded against that scale).
     (2) the same tensors end to end (own back-end gradient).  The random-weight back-end with BatchNorm over 4 utterances turns the
-        3e-2 bf16 feature error into a 35-65 % change of its feature gradient (cosine 0.89 - 0.97, measured on two inputs); given identical
-        features it matches the oracle to 1e-3 (tests/test_gpu_backend.py), so this bound only says the chain holds together: cosine > 0.8.
+        3e-2 bf16 feature error into a 35-65 % change of its feature gradient (cosine 0.89 - 0.97, measured on two inputs; bound 0.8); given
+        identical features it matches the oracle to 1e-3 (tests/test_gpu_backend.py).  Downstream of that gradient the bounds are those of
+        (1): the oracle's front-end autograd is driven with the device's own feature gradient (cosine >= 0.999, 3 % max-relative).
     (3) bs 64 = 16 copies of those 4 utterances: the mean-loss gradient must equal the bs-4 one (BatchNorm statistics of a replicated
         batch are the same), which checks the bench-size step through linearity.
     Dropout off on both sides; the back-end runs its exact-f32 mode, XLS-R the bf16 MFMA path."""
@@ -155,8 +156,9 @@ def test_finetune_300m_step_gradients_match_oracle_autograd_and_bs64_is_linear(o
     feats.retain_grad()
     emb, out = aasist_ref.backend_forward(feats, pb, train=True)
     loss = losses_ref.descriptiveness_loss(out, labels)
-    loss.backward()
-    loss, dfe_ref = float(loss.detach()), feats.grad
+    loss.backward(retain_graph=True)                         # (the front-end graph is walked a second time in (2) with the device's own feature gradient)
+    loss, dfe_ref = float(loss.detach()), feats.grad.clone()
+    ref_grads = {k: pr[k].grad.clone() for k in CHECKED}
     gscale = max(float(pr[k].grad.norm()) / pr[k].grad.numel() ** 0.5 for k in CHECKED)         # largest rms gradient among the checked tensors
     # ---- HIP path
     model = AModel(None, "cuda", ssl_cfg=xlsr.XlsrConfig.xlsr_300m(), ssl_state_dict=p, backend_state_dict=pb, finetune_ssl="full", backend_compute="f32")
@@ -182,13 +184,28 @@ def test_finetune_300m_step_gradients_match_oracle_autograd_and_bs64_is_linear(o
         c, e = _grad_check(gi[k], r, k, cos_min=0.999, rel_max=3e-2)
         worst = (min(worst[0], c), max(worst[1], e))
     print("full-size front-end backward: worst cosine %.5f, worst max-relative error %.4f" % worst)
-    # (2) end to end
+    # (2) end to end.  The only loose bound left is on the back-end's feature gradient itself (BatchNorm over 4 utterances of a random-weight
+    # back-end amplifies the 3e-2 bf16 feature error: cosine 0.89 - 0.97 measured; with identical features that gradient matches the oracle to
+    # 1e-3, tests/test_gpu_backend.py).  Everything downstream of it is held tightly: the oracle's front-end autograd is driven with the
+    # DEVICE's feature gradient, so a missing or wrong branch in the chain back-end gradient -> 24 layers -> conv stack shows at the 3 % level.
     l4, g4, dfe4 = step(wav, labels)
     assert abs(l4 - loss) < 5e-2 * max(1.0, abs(loss)), (l4, loss)       # bf16 features through a random-weight back-end: 2.3 % measured
     _grad_check(dfe4, dfe_ref, "dfeats", cos_min=0.8, rel_max=1.0)
+    for v in pr.values():
+        v.grad = None
+    feats.backward(dfe4.detach().cpu().float())
+    gscale2 = max(float(pr[k].grad.norm()) / pr[k].grad.numel() ** 0.5 for k in CHECKED)
+    worst2 = (1.0, 0.0)
     for k in CHECKED:
-        if float(pr[k].grad.norm()) / pr[k].grad.numel() ** 0.5 >= 1e-2 * gscale:
-            _grad_check(g4[k], pr[k].grad, "e2e " + k, cos_min=0.8, rel_max=1.0)
+        r = pr[k].grad
+        if float(r.norm()) / r.numel() ** 0.5 < 1e-2 * gscale2:
+            assert float((g4[k].cpu() - r).abs().max()) < 0.05 * gscale2, k
+            continue
+        c, e = _grad_check(g4[k], r, "e2e " + k, cos_min=0.999, rel_max=3e-2)
+        worst2 = (min(worst2[0], c), max(worst2[1], e))
+    print("full-size end-to-end chain (device feature gradient through the oracle's front-end autograd): worst cosine %.5f, worst max-relative error %.4f" % worst2)
+    for k in CHECKED:                                        # restore the oracle's own end-to-end gradients for (3)
+        pr[k].grad = ref_grads[k]
     # (3) bs 64 = 16 copies: same mean-loss gradient.  With the oracle's feature gradient (each copy carries 1/16 of it) the bench-size
     # front-end step must reproduce the bs-4 gradients to bf16 round-off (other GEMM kernels are selected at M = 12736 than at M = 796);
     # end to end the replicated batch goes through the same sensitive back-end as in (2).
