@@ -491,6 +491,9 @@ int occ_gemm_tn_pair(const occ_gemm_tn_desc* d0, const occ_gemm_tn_desc* d1, voi
     OCC_CHECK_ARG(d0 && d1, "occ_gemm_tn_pair: null descriptor");
     const occ_gemm_tn_desc* d[2] = {d0, d1};
     bool ok = d0->M == d1->M;
+    // reduction rows beyond the last whole 64-row K-tile (variable-length groups: M = 12 * T is rarely a multiple of 64) go through the
+    // small-tile kernel per product afterwards, as occ_gemm_tn does; the paired launch covers rows [0, rows64)
+    const long long rows64 = d0->M - d0->M % 64;
     for (int p = 0; p < 2 && ok; ++p) {
         const occ_gemm_tn_desc* q = d[p];
         ok = q->A && q->B && q->C && q->compute == OCC_BF16 && q->a_dtype == OCC_BF16 && q->b_dtype == OCC_BF16 && q->b_nseg <= 1 && q->ldc >= q->N2 &&
@@ -505,9 +508,19 @@ int occ_gemm_tn_pair(const occ_gemm_tn_desc* d0, const occ_gemm_tn_desc* d1, voi
             am[p] = to_rowmap(d[p]->a_map); bm[p] = to_rowmap(d[p]->b_map);
             ma[p] = max_row_off(d[p]->a_map, d[p]->M) + d[p]->N1; mb[p] = max_row_off(d[p]->b_map, d[p]->M) + d[p]->N2;
         }
-        if (occ_tn_p8_pair_try(d0->M, N1, N2, A, am, B, bm, C, ldc, alpha, d0->workspace, d0->workspace_bytes, ma, mb, (hipStream_t)stream) == 1) {
-            for (int p = 0; p < 2; ++p)
+        const bool tail_ok = rows64 == d0->M || (N1[0] % 8 == 0 && N2[0] % 8 == 0 && N1[1] % 8 == 0 && N2[1] % 8 == 0);
+        if (tail_ok && occ_tn_p8_pair_try(rows64, N1, N2, A, am, B, bm, C, ldc, alpha, d0->workspace, d0->workspace_bytes, ma, mb, (hipStream_t)stream) == 1) {
+            for (int p = 0; p < 2; ++p) {
                 if (d[p]->colsum) launch_colsum_bf16_vec((const unsigned short*)d[p]->A, am[p], d[p]->M, d[p]->N1, (float*)d[p]->colsum, d[p]->alpha, (hipStream_t)stream);
+                if (rows64 < d[p]->M) {
+                    TnArgs t;
+                    t.M = d[p]->M; t.N1 = N1[p]; t.N2 = N2[p]; t.A = A[p]; t.amap = am[p]; t.B = B[p]; t.bmap = bm[p]; t.nseg = 1; t.seg_len = N2[p]; t.seg_stride = 0;
+                    t.C = C[p]; t.ldc = ldc[p]; t.alpha = alpha[p]; t.colsum = nullptr; t.atomic = 0; t.m_first = rows64; t.rows_per_split = SLD;
+                    t.ngroups = 1; t.a_gs = t.b_gs = t.c_gs = 0;
+                    t.t1 = (int)occ_cdiv(N1[p], TD); t.t2 = (int)occ_cdiv(N2[p], TD);
+                    hipLaunchKernelGGL(gemm_tn_dma_kernel<1>, dim3((unsigned)(t.t1 * t.t2)), dim3(THREADS), 0, (hipStream_t)stream, t);
+                }
+            }
             OCC_LAUNCH_CHECK("occ_gemm_tn_pair");
             return OCC_OK;
         }

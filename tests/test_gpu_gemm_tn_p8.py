@@ -76,10 +76,11 @@ def test_tn_p8_random_data_and_race_screen():
 
 
 @pytest.mark.parametrize("M,shapes", [(12736, ((1024, 1024), (3072, 1024))), (12736, ((1024, 4096), (4096, 1024))), (2048, ((256, 256), (512, 256))),
-                                      (1000, ((256, 256), (256, 512)))])
+                                      (1000, ((256, 256), (256, 512))), (6368, ((1280, 1280), (3840, 1280))), (2388, ((1024, 4096), (4096, 1024)))])
 def test_tn_p8_pair_launch_exact(M, shapes):
     """occ_gemm_tn_pair: two weight (+ bias) gradients with the same reduction rows in one launch (out-proj with qkv, fc2 with fc1 at bs 64;
-    a small pair; a row count that is not a multiple of 64, which runs as two single launches).  Integer operands: exact, with
+    a small pair; a row count under 1024, which runs as two single launches; row counts that are not multiples of 64 -- the paired launch
+    covers the whole 64-row K-tiles and the M % 64 tail rows go through the small-tile kernel per product).  Integer operands: exact, with
     accumulation onto non-zero C and bias buffers."""
     from occm_amd import backend_ops as K
     ops_in, refs, outs = [], [], []
