@@ -64,7 +64,7 @@ def canonical_len(T):
 
 
 def embed_dataset(model, dataloader, device, batch_size=1, rank=0, world=1):
-    """(emb [N,160], logits [N,2]) of every utterance, in dataset order.
+    """(emb [N,160] (AASIST) or [N,128] (SE-ResNet34), logits [N,2]) of every utterance, in dataset order.
 
     world > 1 (one process per GPU, torch.distributed initialised): rank r embeds the utterances whose position p has p % world == r
     -- the loader must then be built over ``shard_dataset(dataset, rank, world)`` -- and a sum all-reduce of the zero-initialised
@@ -79,7 +79,8 @@ def embed_dataset(model, dataloader, device, batch_size=1, rank=0, world=1):
     ds = dataloader.dataset
     n_local = len(ds)
     n = getattr(ds, "full_len", n_local)                     # shard_dataset records the length of the whole set
-    embs, logits = torch.zeros(n, 160, device=device), torch.zeros(n, 2, device=device)
+    width = int(getattr(model, "emb_dim", 160))              # AASIST: 160 (5 x 32 readouts); SE-ResNet34: 128
+    embs, logits = torch.zeros(n, width, device=device), torch.zeros(n, 2, device=device)
     pending = {}
 
     def flush(items):
@@ -128,8 +129,42 @@ def shard_dataset(dataset, rank, world):
     return dataset if world <= 1 else _Shard(dataset, rank, world)
 
 
-def create_reference_embedding2(model, dataloader, device, cache=True, batch_size=1, rank=0, world=1):
-    """oc_classifier.py:159-202: mean embedding of the bona-fide set, threshold = largest distance to it."""
+class ExtractorEncoder:
+    """The two-model form of the reference's scoring functions (oc_classifier.py:139-144, 229-234, 281-287):
+    ``emb = extractor(data); emb = emb.unsqueeze(1); encoder(emb)`` -- an SSLModel feature extractor followed by se_resnet34 -- behind the
+    one-model call signature embed_dataset drives."""
+    emb_dim = 128
+
+    def __init__(self, extractor, encoder):
+        self.extractor, self.encoder = extractor, encoder
+
+    def eval(self):
+        self.extractor.eval(); self.encoder.eval()
+        return self
+
+    def __call__(self, data):
+        feats = self.extractor(data)
+        return self.encoder(feats.float().unsqueeze(1))
+
+
+def create_reference_embedding(extractor, encoder, dataloader, device, cache=True, batch_size=1, rank=0, world=1):
+    """oc_classifier.py:113-157: as create_reference_embedding2 with the (extractor, encoder) pair."""
+    return create_reference_embedding2(ExtractorEncoder(extractor, encoder), dataloader, device, cache, batch_size, rank, world, distances_file=None)
+
+
+def score_eval_set_1c1(extractor, encoder, dataloader, device, reference_embedding, threshold, path="scores.txt", batch_size=1, rank=0, world=1):
+    """oc_classifier.py:206-241: one-class scoring with the (extractor, encoder) pair."""
+    return score_eval_set_1c2(ExtractorEncoder(extractor, encoder), dataloader, device, reference_embedding, threshold, path, batch_size, rank, world)
+
+
+def score_eval_set_2c1(extractor, encoder, dataloader, device, path="scores.txt", batch_size=1, rank=0, world=1):
+    """oc_classifier.py:268-291: two-class scoring (the bona-fide logit) with the (extractor, encoder) pair."""
+    return score_eval_set_2c2(ExtractorEncoder(extractor, encoder), dataloader, device, path, batch_size, rank, world)
+
+
+def create_reference_embedding2(model, dataloader, device, cache=True, batch_size=1, rank=0, world=1, distances_file="distances.txt"):
+    """oc_classifier.py:159-202: mean embedding of the bona-fide set, threshold = largest distance to it.  (The reference's AASIST form
+    also appends every distance to distances.txt, :197-199; its two-model form :113-157 does not.)"""
     if cache and os.path.exists("reference_embedding.pt") and os.path.exists("threshold.pt"):
         print("Loading reference embedding and threshold...")
         return torch.load("reference_embedding.pt"), torch.load("threshold.pt")
@@ -137,8 +172,8 @@ def create_reference_embedding2(model, dataloader, device, cache=True, batch_siz
     embs, _ = embed_dataset(model, dataloader, device, batch_size, rank, world)      # [N,160]
     reference_embedding = embs.mean(dim=0, keepdim=True)            # [1,160] like torch.mean(torch.stack(..), 0)
     dist = ops.pairwise_dist(reference_embedding.reshape(-1).contiguous(), embs.contiguous())
-    if rank == 0:
-        with open("distances.txt", "a") as f:
+    if rank == 0 and distances_file:
+        with open(distances_file, "a") as f:
             for d in dist.tolist():
                 f.write(f"{d}\n")
     threshold = dist.max()

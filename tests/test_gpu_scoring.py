@@ -82,6 +82,58 @@ def test_reference_embedding_threshold_and_scores_match_oracle(tmp_path, monkeyp
         assert int(flag) == int(float(dist) > float(thr))
 
 
+def test_extractor_encoder_scoring_variants_match_oracle(tmp_path, monkeypatch):
+    """The two-model scoring functions (oc_classifier.py:113-157 create_reference_embedding, :206-241 score_eval_set_1c1, :268-291
+    score_eval_set_2c1): XLS-R extractor + SE-ResNet34 encoder, f32 path, against xlsr_ref -> senet_ref on the same files."""
+    from oracle import losses_ref, senet_ref, xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.data_utils_SSL import load_audio
+    from occm_amd.models import xlsr
+    from occm_amd.models.senet import se_resnet34
+    from occm_amd.oc_classifier import ASVDataset, create_reference_embedding, score_eval_set_1c1, score_eval_set_2c1
+    from torch.utils.data import DataLoader
+    monkeypatch.chdir(tmp_path)
+    d = tmp_path / "audio"; d.mkdir()
+    tr_lines, ev_lines = [], []
+    for i in range(4):
+        _write_wav(str(d / f"T{i}.wav"), 9000 + 500 * i, 20 + i)
+        tr_lines.append(f"LA_{i} T{i} - - {'bonafide' if i != 1 else 'spoof'}")
+    for i in range(3):
+        _write_wav(str(d / f"E{i}.wav"), 8200 + 900 * i, 70 + i)
+        ev_lines.append(f"E{i}")
+    (tmp_path / "train.txt").write_text("\n".join(tr_lines) + "\n")
+    (tmp_path / "eval.txt").write_text("\n".join(ev_lines) + "\n")
+    kw = dict(dim=1024, ffn=512, heads=16, layers=1)
+    rcfg, cfg = xlsr_ref.XlsrConfig(**kw), xlsr.XlsrConfig(**kw)
+    px = fill_like(xlsr_ref.param_shapes(rcfg), seed=3)
+    ps = fill_like(senet_ref.param_shapes(), seed=1)
+    extractor = xlsr.SSLModel("cuda", state_dict=px, cfg=cfg, dtype=torch.float32)
+    encoder = se_resnet34(state_dict=ps, device="cuda")
+    tr = DataLoader(ASVDataset(str(tmp_path / "train.txt"), str(d)), batch_size=1, shuffle=False)
+    ev = DataLoader(ASVDataset(str(tmp_path / "eval.txt"), str(d), eval=True), batch_size=1, shuffle=False)
+    ref_emb, thr = create_reference_embedding(extractor, encoder, tr, "cuda")
+    assert tuple(ref_emb.shape) == (1, 128) and os.path.exists("reference_embedding.pt") and os.path.exists("threshold.pt") and not os.path.exists("distances.txt")
+    score_eval_set_1c1(extractor, encoder, ev, "cuda", ref_emb, thr, path="scores_1c1.txt")
+    score_eval_set_2c1(extractor, encoder, ev, "cuda", path="scores_2c1.txt")
+
+    def oracle_out(path):
+        with torch.no_grad():
+            f = xlsr_ref.extract_feat(torch.tensor(load_audio(path)[0])[None], px, rcfg)
+            return senet_ref.senet34_forward(f.unsqueeze(1), ps, train=False)
+    embs = torch.stack([oracle_out(str(d / f"T{i}.wav"))[0] for i in (0, 2, 3)])
+    o_ref, o_thr, _ = losses_ref.reference_embedding_and_threshold(embs)
+    torch.testing.assert_close(ref_emb.cpu(), o_ref, rtol=1e-3, atol=1e-3)
+    assert abs(float(thr) - float(o_thr)) < 2e-3
+    l1, l2 = open("scores_1c1.txt").read().splitlines(), open("scores_2c1.txt").read().splitlines()
+    assert len(l1) == 3 and len(l2) == 3
+    for i in range(3):
+        emb, out = oracle_out(str(d / f"E{i}.wav"))
+        dist, flag = l1[i].split(",")
+        assert abs(float(dist) - float(losses_ref.pairwise_l2(o_ref, emb))) < 2e-3 and l1[i].endswith(" ")
+        assert int(flag) == int(float(dist) > float(thr))
+        assert abs(float(l2[i]) - float(out[0][0])) < 2e-3
+
+
 def test_bucketed_batch_scoring_equals_one_at_a_time(tmp_path, monkeypatch):
     """--batch_size 3: utterances are grouped by frame count and cropped to the samples those frames depend on; scores.txt, the reference
     embedding and the threshold must equal the reference's one-utterance loop (f32 front-end: to 2e-4; the two differ only in the GEMM

@@ -96,6 +96,22 @@ def test_asvdataset_modes(tmp_path):
     assert x.shape == (600,) and y.tolist() == [0]
 
 
+def test_oc_classifier_exposes_every_scoring_function_of_the_reference():
+    """oc_classifier.py:113-312: the six scoring functions, their leading positional parameters in the reference's order (extra keyword
+    parameters -- batch_size, rank, world, path -- come after them)."""
+    import inspect
+    from occm_amd import oc_classifier as oc
+    want = {"create_reference_embedding": ["extractor", "encoder", "dataloader", "device"],
+            "create_reference_embedding2": ["model", "dataloader", "device"],
+            "score_eval_set_1c1": ["extractor", "encoder", "dataloader", "device", "reference_embedding", "threshold"],
+            "score_eval_set_1c2": ["model", "dataloader", "device", "reference_embedding", "threshold"],
+            "score_eval_set_2c1": ["extractor", "encoder", "dataloader", "device"],
+            "score_eval_set_2c2": ["model", "dataloader", "device"]}
+    for name, lead in want.items():
+        params = list(inspect.signature(getattr(oc, name)).parameters)
+        assert params[:len(lead)] == lead, (name, params)
+
+
 def test_rawboost_flag_defaults_match_reference():
     from occm_amd.oc_training import rawboost_args
     a = rawboost_args()
