@@ -7,7 +7,7 @@
 //     S = Q.K^T and dP = dO.V^T           (A = Q / dO rows from the LDS slice, B = K / V fragments)     -> lane: 4 queries x 1 key
 //     P = exp2(S*c - lse[q]),  dS = P * (dP - delta[q])         (lse from the forward, delta = rowsum(dO * O) computed per slice)
 //     dV^T += dO^T.P,  dK^T += Q^T.dS     (A = transposing reads of the dO / Q slice, B = the packed P / dS registers)
-//     dS -> LDS [32][keys];  dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]    (A = transposing reads of the K image, B = dS rows)
+//     dS^T -> LDS [keys][32];  dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]    (A, B = transposing reads of the K image / the dS^T rows)
 // k-slot (g, u, j) of a 32-deep contraction <-> row 16u + 4g + j on both operands of the three transposed products.
 // The Q / dO slices are row-major [32][HD] (next slice prefetched into registers under the current step); 128-byte rows (HD = 64)
 // are XOR-swizzled so that both the row reads (ds_read_b128) and the transposing reads are bank-conflict free.
@@ -36,7 +36,13 @@ template <int HD> struct AbCfg {
     static constexpr int ROWB = HD == 64 ? 128 : 208;  // LDS row bytes of the Q / dO slices and the K image (96 elements + pad for HD = 80)
     static constexpr bool SWZ = HD == 64;
 };
-constexpr int AB_KEYS = 256, AB_DS_STRIDE = AB_KEYS + 8;      // dS rows: 16-byte aligned, 8-element pad
+constexpr int AB_KEYS = 256;
+// dS of a 32-query step is staged TRANSPOSED, [key][32 queries] bf16 = 64-byte rows: the lane that computed dS for 4 consecutive queries of
+// one key stores them with ONE 8-byte write (it was four 2-byte writes into [query][key] rows), and dQ's B operand (column = query,
+// k = keys) comes back through the same transposing read that serves the K image.  The two 32-byte halves (query tiles) of a row swap
+// places every four rows, so the eight rows a 32-lane pass of the transposing read touches fall on disjoint banks.
+constexpr int AB_DS_ROWB = 64, AB_DS_BYTES = AB_KEYS * AB_DS_ROWB;
+__device__ __forceinline__ unsigned ab_ds_off(int key, int qt) { return (unsigned)(key * AB_DS_ROWB + ((qt ^ ((key >> 2) & 1)) << 5)); }
 
 // byte offset of 16-byte chunk c of row r in a slice / image
 template <int HD> __device__ __forceinline__ unsigned ab_off(int r, int c) {
@@ -59,8 +65,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
     unsigned char* Kimg = sm;                                        // [256][ROWB]
     unsigned char* Qs = Kimg + AB_KEYS * ROWB;                       // [2][32][ROWB]
     unsigned char* dOs = Qs + 2 * 32 * ROWB;                         // [2][32][ROWB]
-    unsigned short* dSs0 = reinterpret_cast<unsigned short*>(dOs + 2 * 32 * ROWB);      // [2][32][AB_DS_STRIDE]: step st writes buffer st & 1
-    float* lse_s = reinterpret_cast<float*>(dSs0 + 2 * 32 * AB_DS_STRIDE);              // [2][32]
+    unsigned char* dSs0 = dOs + 2 * 32 * ROWB;                                          // [2][256 keys][64 B]: step st writes buffer st & 1
+    float* lse_s = reinterpret_cast<float*>(dSs0 + 2 * AB_DS_BYTES);                    // [2][32]
     float* dlt_s = lse_s + 64;                                                          // [2][32]
     const int D = H * HD;
     const int bh = blockIdx.x, b = bh / H, h = bh % H, kb = blockIdx.y;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
     }
     if (tid < 64) dlt_s[tid] = 0.f;
     // dS columns of key tiles that are not in use are never written but can be read by the last 32-key step of dQ (against zero K rows)
-    for (int idx = tid; idx < 2 * 32 * AB_DS_STRIDE / 8; idx += 512) reinterpret_cast<uint4*>(dSs0)[idx] = make_uint4(0, 0, 0, 0);
+    for (int idx = tid; idx < 2 * AB_DS_BYTES / 16; idx += 512) reinterpret_cast<uint4*>(dSs0)[idx] = make_uint4(0, 0, 0, 0);
     prefetch(0);
     __syncthreads();
     commit(0);
@@ -170,31 +176,33 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
     // bsum (one key block only): per (batch, head) column sums of the stored (bf16-rounded) dq / dk / dv -- the q|k|v bias gradients,
     // which were a separate pass over dqkv.  dq: this wave's (q tile, d tile) pairs accumulate over the steps.
     f32x4 dqs[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    auto dq_phase = [&](const int q0, const unsigned short* dSs) {
+    auto dq_phase = [&](const int q0, const unsigned dss) {        // dss: LDS byte address of the step's dS buffer
         int slot = 0;
         for (int pr = wave; pr < 2 * DT; pr += 8, ++slot) {
             const int qt = pr / DT, dt = pr - qt * DT;
             f32x4 qacc = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int nks = (nkeys + 31) >> 5;
-            for (int ks0 = 0; ks0 < nks; ks0 += 4) {   // four 32-key steps per wait (steps beyond the block read zero K rows: harmless)
-                u32x2 kr[4][2]; uint2 sr[4][2];
+            // dS^T rows ks*32 + 4g + q4 (+16): the half swap depends on (row >> 2) & 1 = g & 1 only, so the address is a lane constant + ks * 2 KiB
+            const unsigned dsq = dss + (unsigned)((4 * g + q4) * AB_DS_ROWB + ((qt ^ (g & 1)) << 5) + p4 * 8);
+            constexpr int UB = HD == 64 ? 4 : 2;       // 32-key steps per wait (steps beyond the block read zero K rows: harmless); HD = 80 has no registers for four
+            for (int ks0 = 0; ks0 < nks; ks0 += UB) {
+                u32x2 kr[UB][2], sr[UB][2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UB; ++u) {
                     const int ks = ks0 + u < 8 ? ks0 + u : 7;
                     const int r0 = ks * 32 + 4 * g + q4;
                     unsigned offa, offb;
                     if (C::SWZ) { offa = (unsigned)(r0 * 128 + ((dt ^ ((r0 >> 1) & 3)) << 5) + p4 * 8); offb = (unsigned)((r0 + 16) * 128 + ((dt ^ (((r0 + 16) >> 1) & 3)) << 5) + p4 * 8); }
                     else { offa = (unsigned)(r0 * ROWB + dt * 32 + p4 * 8); offb = offa + 16 * ROWB; }
                     kr[u][0] = ab_tr_read(lds0 + offa); kr[u][1] = ab_tr_read(lds0 + offb);
-                    sr[u][0] = *reinterpret_cast<const uint2*>(dSs + (qt * 16 + fr) * AB_DS_STRIDE + ks * 32 + 4 * g);
-                    sr[u][1] = *reinterpret_cast<const uint2*>(dSs + (qt * 16 + fr) * AB_DS_STRIDE + ks * 32 + 16 + 4 * g);
+                    sr[u][0] = ab_tr_read(dsq + ks * (32 * AB_DS_ROWB)); sr[u][1] = ab_tr_read(dsq + ks * (32 * AB_DS_ROWB) + 16 * AB_DS_ROWB);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UB; ++u) {
                     if (ks0 + u >= nks) continue;
-                    const u32x4 ka = (u32x4){kr[u][0][0], kr[u][0][1], kr[u][1][0], kr[u][1][1]}, sbv = (u32x4){sr[u][0].x, sr[u][0].y, sr[u][1].x, sr[u][1].y};
+                    const u32x4 ka = (u32x4){kr[u][0][0], kr[u][0][1], kr[u][1][0], kr[u][1][1]}, sbv = (u32x4){sr[u][0][0], sr[u][0][1], sr[u][1][0], sr[u][1][1]};
                     qacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, sbv), qacc, 0, 0, 0);
                 }
             }
@@ -219,11 +227,11 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
     };
     for (int st = 0; st < nstep; ++st) {
         const int q0 = st * 32, buf = st & 1;
-        unsigned short* dSs = dSs0 + buf * 32 * AB_DS_STRIDE;
+        unsigned char* dSs = dSs0 + buf * AB_DS_BYTES;
         if (st + 1 < nstep) prefetch(q0 + 32);
         __syncthreads();                               // slice `buf` (Q, dO, lse, delta) and the previous step's dS are complete
         if (CH != 8 && tid < 32) dlt_s[(buf ^ 1) * 32 + tid] = 0.f;  // (atomics form only) the other buffer's delta is re-accumulated by the next commit
-        if (st > 0) dq_phase(q0 - 32, dSs0 + (buf ^ 1) * 32 * AB_DS_STRIDE);
+        if (st > 0) dq_phase(q0 - 32, lds0 + (unsigned)(dSs0 - sm) + (buf ^ 1) * AB_DS_BYTES);
         const unsigned qs0 = lds0 + (unsigned)(Qs - sm) + buf * 32 * ROWB, ds0 = lds0 + (unsigned)(dOs - sm) + buf * 32 * ROWB;
         unsigned pp[2][4], ds[2][4];                   // [key tile][packed bf16 pairs]: slots j < 4 from q-tile 0, j >= 4 from q-tile 1
         float lq[2][4], dq_[2][4];                     // lse / delta of the lane's eight query rows: read once per step, not once per key tile
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ql = qt * 16 + g * 4 + r;
+                    [[maybe_unused]] const int ql = qt * 16 + g * 4 + r;
                     const float p = key < nkeys ? __builtin_amdgcn_exp2f(sacc[r] * c2 - lq[qt][r]) : 0.f;
                     float pd = p, dpd = dpacc[r];
                     if constexpr (DROP) {
@@ -261,7 +269,6 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
                     }
                     pv[qt][r] = pd;
                     dsv[qt][r] = p * (dpd - dq_[qt][r]);
-                    dSs[ql * AB_DS_STRIDE + key] = f32_to_bf16_bits(dsv[qt][r]);
                 }
             }
 #pragma unroll
@@ -271,30 +278,42 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
                 ds[kk][e] = (unsigned)f32_to_bf16_bits(dsv[0][2 * e]) | ((unsigned)f32_to_bf16_bits(dsv[0][2 * e + 1]) << 16);
                 ds[kk][2 + e] = (unsigned)f32_to_bf16_bits(dsv[1][2 * e]) | ((unsigned)f32_to_bf16_bits(dsv[1][2 * e + 1]) << 16);
             }
+            // dS^T[key][queries 4g .. 4g+3 of q-tile qt]: the packed pairs as they are
+            // ((key >> 2) & 1 = (fr >> 2) & 1: the two halves' places are lane constants)
+            *reinterpret_cast<uint2*>(dSs + key * AB_DS_ROWB + (((fr >> 2) & 1) << 5) + g * 8) = make_uint2(ds[kk][0], ds[kk][1]);
+            *reinterpret_cast<uint2*>(dSs + key * AB_DS_ROWB + ((((fr >> 2) & 1) ^ 1) << 5) + g * 8) = make_uint2(ds[kk][2], ds[kk][3]);
         }
         // dV^T += dO^T . P ; dK^T += Q^T . dS   (contraction over the 32 queries of the step: slot (g, u, j) <-> query 16u + 4g + j)
         if (wave < nkt) {
             // all transposing reads of the step first (one wait), then the MFMAs: block dt (32 bytes = 16 d) of rows 4g + q4 (+16); the
             // swizzle moves whole 32-byte blocks, so the 8-byte piece p4 stays in place
-            u32x2 dfr[DT][2], qfr[DT][2];
+            // (HD = 80: in two batches of d tiles -- 40 fragment registers at once do not fit beside the 128 accumulator / operand registers)
+            constexpr int DB = HD == 64 ? DT : 3;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                unsigned offa, offb;
-                if (C::SWZ) { const int r0 = 4 * g + q4; offa = (unsigned)(r0 * 128 + ((dt ^ ((r0 >> 1) & 3)) << 5) + p4 * 8); offb = (unsigned)((r0 + 16) * 128 + ((dt ^ (((r0 + 16) >> 1) & 3)) << 5) + p4 * 8); }
-                else { offa = (unsigned)((4 * g + q4) * ROWB + dt * 32 + p4 * 8); offb = offa + 16 * ROWB; }
-                dfr[dt][0] = ab_tr_read(ds0 + offa); dfr[dt][1] = ab_tr_read(ds0 + offb); qfr[dt][0] = ab_tr_read(qs0 + offa); qfr[dt][1] = ab_tr_read(qs0 + offb);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+            for (int d0 = 0; d0 < DT; d0 += DB) {
+                u32x2 dfr[DB][2], qfr[DB][2];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const u32x4 da = (u32x4){dfr[dt][0][0], dfr[dt][0][1], dfr[dt][1][0], dfr[dt][1][1]}, qa = (u32x4){qfr[dt][0][0], qfr[dt][0][1], qfr[dt][1][0], qfr[dt][1][1]};
+                for (int i = 0; i < DB; ++i) {
+                    const int dt = d0 + i < DT ? d0 + i : DT - 1;
+                    unsigned offa, offb;
+                    if (C::SWZ) { const int r0 = 4 * g + q4; offa = (unsigned)(r0 * 128 + ((dt ^ ((r0 >> 1) & 3)) << 5) + p4 * 8); offb = (unsigned)((r0 + 16) * 128 + ((dt ^ (((r0 + 16) >> 1) & 3)) << 5) + p4 * 8); }
+                    else { offa = (unsigned)((4 * g + q4) * ROWB + dt * 32 + p4 * 8); offb = offa + 16 * ROWB; }
+                    dfr[i][0] = ab_tr_read(ds0 + offa); dfr[i][1] = ab_tr_read(ds0 + offb); qfr[i][0] = ab_tr_read(qs0 + offa); qfr[i][1] = ab_tr_read(qs0 + offb);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    if (wave + 8 * kk >= nkt) continue;
-                    const u32x4 pbv = (u32x4){pp[kk][0], pp[kk][1], pp[kk][2], pp[kk][3]}, sbv = (u32x4){ds[kk][0], ds[kk][1], ds[kk][2], ds[kk][3]};
-                    dvacc[dt][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, da), __builtin_bit_cast(bf16x8, pbv), dvacc[dt][kk], 0, 0, 0);
-                    dkacc[dt][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qa), __builtin_bit_cast(bf16x8, sbv), dkacc[dt][kk], 0, 0, 0);
+                for (int i = 0; i < DB; ++i) {
+                    const int dt = d0 + i;
+                    if (dt >= DT) continue;
+                    const u32x4 da = (u32x4){dfr[i][0][0], dfr[i][0][1], dfr[i][1][0], dfr[i][1][1]}, qa = (u32x4){qfr[i][0][0], qfr[i][0][1], qfr[i][1][0], qfr[i][1][1]};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        if (wave + 8 * kk >= nkt) continue;
+                        const u32x4 pbv = (u32x4){pp[kk][0], pp[kk][1], pp[kk][2], pp[kk][3]}, sbv = (u32x4){ds[kk][0], ds[kk][1], ds[kk][2], ds[kk][3]};
+                        dvacc[dt][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, da), __builtin_bit_cast(bf16x8, pbv), dvacc[dt][kk], 0, 0, 0);
+                        dkacc[dt][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qa), __builtin_bit_cast(bf16x8, sbv), dkacc[dt][kk], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -304,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
         if (st + 1 < nstep) commit(buf ^ 1);
     }
     __syncthreads();
-    dq_phase((nstep - 1) * 32, dSs0 + ((nstep - 1) & 1) * 32 * AB_DS_STRIDE);
+    dq_phase((nstep - 1) * 32, lds0 + (unsigned)(dSs0 - sm) + ((nstep - 1) & 1) * AB_DS_BYTES);
     // ---- dK, dV of this wave's keys: lane holds 4 consecutive d of one key
     f32x4 dks[BIAS ? DT : 1], dvs[BIAS ? DT : 1];
 #pragma unroll
@@ -418,7 +437,7 @@ int launch_attention_bwd2(const void* qkv, const void* o, const void* dout, cons
                           int64_t ld_qkv, int64_t ld_o, float scale, hipStream_t s, const unsigned char* keep = nullptr, float p = 0.f, float* dbias = nullptr,
                           float* bias_ws = nullptr) {
     using C = AbCfg<HD>;
-    const size_t shm = (size_t)AB_KEYS * C::ROWB + 4 * 32 * C::ROWB + 2 * 32 * AB_DS_STRIDE * 2 + 128 * 4;
+    const size_t shm = (size_t)AB_KEYS * C::ROWB + 4 * 32 * C::ROWB + 2 * AB_DS_BYTES + 128 * 4;
     hipError_t e = hipFuncSetAttribute((const void*)attention_bwd2_kernel<HD, DROP, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) { occ_set_error("occ_attention_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
     const int64_t nkb = occ_cdiv(T, AB_KEYS);
