@@ -212,6 +212,10 @@ typedef struct occ_gemm_tn_desc {
      * A + g*a_group_stride, B + g*b_group_stride, C + g*c_group_stride, strides in elements); bf16 operands / bf16 MFMA only,
      * N1 >= 64, colsum must be NULL (sum the whole A once with occ_colsum).  0 / 1: one product.                                  */
     int64_t n_groups, a_group_stride, b_group_stride, c_group_stride;
+    /* Hint, non-zero: C holds zeros (a gradient buffer cleared since its last use).  The large bf16 kernels then STORE alpha * product
+     * instead of reading C back and adding -- the same result (0 + x = x) without the 4 bytes per element of read traffic.  Paths that
+     * accumulate with atomics ignore it.                                                                                        */
+    int c_is_zero;
 } occ_gemm_tn_desc;
 int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream);
 /* Two weight gradients with the same reduction rows M (out-proj with qkv, fc2 with fc1 of one transformer layer) in ONE launch when both

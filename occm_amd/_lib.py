@@ -46,7 +46,8 @@ class GemmTnDesc(ctypes.Structure):
                 ("C", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("alpha", ctypes.c_float), ("colsum", ctypes.c_void_p),
                 ("a_dtype", ctypes.c_int), ("b_dtype", ctypes.c_int), ("compute", ctypes.c_int),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
-                ("n_groups", ctypes.c_int64), ("a_group_stride", ctypes.c_int64), ("b_group_stride", ctypes.c_int64), ("c_group_stride", ctypes.c_int64)]
+                ("n_groups", ctypes.c_int64), ("a_group_stride", ctypes.c_int64), ("b_group_stride", ctypes.c_int64), ("c_group_stride", ctypes.c_int64),
+                ("c_is_zero", ctypes.c_int)]
 
 
 _P = ctypes.c_void_p

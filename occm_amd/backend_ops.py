@@ -42,9 +42,10 @@ def tn_workspace():
     return _TN_WS[key]
 
 
-def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsum_out=None, a_bf16=False, b_bf16=False, bf16_mfma=False, groups=None):
+def gemm_tn(M, N1, N2, A, a_map, Bm, b_map, C, ldc, b_seg=None, alpha=1.0, colsum_out=None, a_bf16=False, b_bf16=False, bf16_mfma=False, groups=None, c_is_zero=False):
     """groups = (n_groups, a_stride, b_stride, c_stride) in elements: that many independent products in one launch (grouped conv)."""
     d = GemmTnDesc()
+    d.c_is_zero = 1 if c_is_zero else 0
     if groups is not None:
         d.n_groups, d.a_group_stride, d.b_group_stride, d.c_group_stride = [int(x) for x in groups]
     if a_bf16 and b_bf16 and bf16_mfma and N1 % 256 == 0 and N2 % 256 == 0 and M >= 1024:
@@ -84,11 +85,13 @@ def _tn_desc_bf16(M, N1, N2, A, a_map, Bm, b_map, C, ldc, colsum_out, ws):
     return d
 
 
-def gemm_tn_pair(M, first, second):
+def gemm_tn_pair(M, first, second, c_is_zero=False):
     """Two bf16 weight gradients with the same reduction rows in one launch where the library can (occ_gemm_tn_pair); first / second =
-    (N1, N2, A, a_map, B, b_map, C, ldc, colsum_out)."""
+    (N1, N2, A, a_map, B, b_map, C, ldc, colsum_out).  c_is_zero: both C hold zeros (gradient buffers cleared since their last use) -- the
+    slab reduce then stores instead of reading C back (occ_gemm_tn_desc.c_is_zero)."""
     ws = tn_workspace()
     d0, d1 = _tn_desc_bf16(M, *first, ws), _tn_desc_bf16(M, *second, ws)
+    d0.c_is_zero = d1.c_is_zero = 1 if c_is_zero else 0
     from . import ops
     if ops.PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

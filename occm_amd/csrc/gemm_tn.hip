@@ -470,10 +470,10 @@ static void launch_colsum_bf16_vec(const unsigned short* A, const RowMapI& amap,
 
 // gemm_tn_p8.hip
 int occ_tn_p8_try(long long M, long long N1, long long N2, const void* A, const RowMapI& amap, const void* B, const RowMapI& bmap, float* C, long long ldc,
-                  float alpha, void* workspace, long long workspace_bytes, long long max_a_off, long long max_b_off, hipStream_t s);
+                  float alpha, void* workspace, long long workspace_bytes, long long max_a_off, long long max_b_off, int store, hipStream_t s);
 int occ_tn_p8_pair_try(long long M, const long long* N1, const long long* N2, const void* const* A, const RowMapI* amap, const void* const* B, const RowMapI* bmap,
                        float* const* C, const long long* ldc, const float* alpha, void* workspace, long long workspace_bytes, const long long* max_a_off,
-                       const long long* max_b_off, hipStream_t s);
+                       const long long* max_b_off, const int* store, hipStream_t s);
 
 static long long max_row_off(const occ_rowmap& m, long long M) {       // upper bound of the element offset of any row < M
     const long long nb = (M - 1) / m.rows_per_batch;
@@ -509,7 +509,8 @@ int occ_gemm_tn_pair(const occ_gemm_tn_desc* d0, const occ_gemm_tn_desc* d1, voi
             ma[p] = max_row_off(d[p]->a_map, d[p]->M) + d[p]->N1; mb[p] = max_row_off(d[p]->b_map, d[p]->M) + d[p]->N2;
         }
         const bool tail_ok = rows64 == d0->M || (N1[0] % 8 == 0 && N2[0] % 8 == 0 && N1[1] % 8 == 0 && N2[1] % 8 == 0);
-        if (tail_ok && occ_tn_p8_pair_try(rows64, N1, N2, A, am, B, bm, C, ldc, alpha, d0->workspace, d0->workspace_bytes, ma, mb, (hipStream_t)stream) == 1) {
+        const int store[2] = {d0->c_is_zero != 0, d1->c_is_zero != 0};
+        if (tail_ok && occ_tn_p8_pair_try(rows64, N1, N2, A, am, B, bm, C, ldc, alpha, d0->workspace, d0->workspace_bytes, ma, mb, store, (hipStream_t)stream) == 1) {
             for (int p = 0; p < 2; ++p) {
                 if (d[p]->colsum) launch_colsum_bf16_vec((const unsigned short*)d[p]->A, am[p], d[p]->M, d[p]->N1, (float*)d[p]->colsum, d[p]->alpha, (hipStream_t)stream);
                 if (rows64 < d[p]->M) {
@@ -559,7 +560,7 @@ int occ_gemm_tn(const occ_gemm_tn_desc* d, void* stream) {
         if (nseg == 1 && ngr == 1 && d->N1 >= 128) {
             const long long rows64 = d->M - d->M % 64;
             const int r = occ_tn_p8_try(rows64, d->N1, d->N2, d->A, a.amap, d->B, a.bmap, a.C, a.ldc, a.alpha, d->workspace, d->workspace_bytes,
-                                        max_row_off(d->a_map, d->M) + d->N1, max_row_off(d->b_map, d->M) + d->N2, (hipStream_t)stream);
+                                        max_row_off(d->a_map, d->M) + d->N1, max_row_off(d->b_map, d->M) + d->N2, d->c_is_zero != 0, (hipStream_t)stream);
             if (r < 0) { occ_set_error("occ_gemm_tn: workspace memset failed"); return OCC_ELAUNCH; }
             if (r == 1) {
                 if (a.colsum) launch_colsum_bf16_vec((const unsigned short*)a.A, a.amap, a.M, a.N1, a.colsum, a.alpha, (hipStream_t)stream);

@@ -37,6 +37,7 @@ struct Args {
     int nt;                            // K-tiles (64 rows) in all; piece s takes [s*nt/S, (s+1)*nt/S)
     int plain;                         // both row maps are m * row_stride: the K advance is a scalar add
     float* slabs;                      // [tile][piece][8 waves][32 accumulators][64 lanes] f32x4, pieces > 1 only
+    int store;                         // C is known to hold zeros: store alpha * product instead of read-add-write
 };
 
 template <int OFF> __device__ __forceinline__ u32x2 tr_read(unsigned addr) {
@@ -241,8 +242,8 @@ __device__ __forceinline__ void tn_p8_body(const Args& a, const int vid) {
         for (int i = 0; i < 4; ++i) {
             const long long n2 = n2_0 + wc * 64 + i * 16 + g * 4;
             float* cp = a.C + n1 * a.ldc + n2;
-            f32x4 c = *reinterpret_cast<f32x4*>(cp);
-            c += acc[i][j] * a.alpha;
+            f32x4 c = acc[i][j] * a.alpha;
+            if (!a.store) c += *reinterpret_cast<f32x4*>(cp);
             *reinterpret_cast<f32x4*>(cp) = c;
         }
     }
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_pair_kernel(const ArgsPair 
 
 // C += alpha * sum over pieces of the slabs (reduce_kernel mode): thread = one f32x4 of one (tile, wave, accumulator, lane) slot,
 // i.e. the slab layout itself (coalesced 1 KiB reads per wave and piece), C addressed as the main kernel's epilogue does.
-__global__ __launch_bounds__(256) void tn_p8_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, long long ldc, float alpha, int S, int t1) {
+__global__ __launch_bounds__(256) void tn_p8_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, long long ldc, float alpha, int S, int t1, int store) {
     const int tile = blockIdx.y;
     const int slot = blockIdx.x * 256 + threadIdx.x;          // [wave 8][acc 32][lane 64]
     const int lane = slot & 63, k = (slot >> 6) & 31, wave = slot >> 11;
@@ -274,13 +275,15 @@ __global__ __launch_bounds__(256) void tn_p8_reduce_kernel(const float* __restri
     const int i = k >> 3, j = k & 7, wr = wave >> 2, wc = wave & 3, fr = lane & 15, g = lane >> 4;
     const long long n1 = (long long)(tile % t1) * 256 + wr * 128 + j * 16 + fr, n2 = (long long)(tile / t1) * 256 + wc * 64 + i * 16 + g * 4;
     f32x4* cp = reinterpret_cast<f32x4*>(C + n1 * ldc + n2);
-    *cp = *cp + v * alpha;
+    v = v * alpha;
+    if (!store) v += *cp;                              // (store: C is known to hold zeros -- no read)
+    *cp = v;
 }
 
 // the same for a pair of products sharing S: blockIdx.y < tiles0 -> first product
 __global__ __launch_bounds__(256) void tn_p8_reduce_pair_kernel(const float* __restrict__ slabs0, float* __restrict__ C0, long long ldc0, int t1_0, int tiles0,
                                                                const float* __restrict__ slabs1, float* __restrict__ C1, long long ldc1, int t1_1, float alpha0,
-                                                               float alpha1, int S) {
+                                                               float alpha1, int S, int store0, int store1) {
     const bool second = (int)blockIdx.y >= tiles0;
     const int tile = second ? blockIdx.y - tiles0 : blockIdx.y;
     const float* slabs = second ? slabs1 : slabs0;
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(256) void tn_p8_reduce_pair_kernel(const float* __r
     const long long ldc = second ? ldc1 : ldc0;
     const int t1 = second ? t1_1 : t1_0;
     const float alpha = second ? alpha1 : alpha0;
+    const int store = second ? store1 : store0;
     const int slot = blockIdx.x * 256 + threadIdx.x;
     const int lane = slot & 63, k = (slot >> 6) & 31, wave = slot >> 11;
     const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + (long long)tile * S * 16384 + slot;
@@ -296,7 +300,9 @@ __global__ __launch_bounds__(256) void tn_p8_reduce_pair_kernel(const float* __r
     const int i = k >> 3, j = k & 7, wr = wave >> 2, wc = wave & 3, fr = lane & 15, g = lane >> 4;
     const long long n1 = (long long)(tile % t1) * 256 + wr * 128 + j * 16 + fr, n2 = (long long)(tile / t1) * 256 + wc * 64 + i * 16 + g * 4;
     f32x4* cp = reinterpret_cast<f32x4*>(C + n1 * ldc + n2);
-    *cp = *cp + v * alpha;
+    v = v * alpha;
+    if (!store) v += *cp;
+    *cp = v;
 }
 
 }  // namespace occ_tn_p8
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void tn_p8_reduce_pair_kernel(const float* __r
 // Requirements on top of occ_tn_p8_try's: the same M (a multiple of 64), plain row maps on all four operands, a workspace for the slabs.
 int occ_tn_p8_pair_try(long long M, const long long* N1, const long long* N2, const void* const* A, const RowMapI* amap, const void* const* B, const RowMapI* bmap,
                        float* const* C, const long long* ldc, const float* alpha, void* workspace, long long workspace_bytes, const long long* max_a_off,
-                       const long long* max_b_off, hipStream_t s) {
+                       const long long* max_b_off, const int* store, hipStream_t s) {
     using namespace occ_tn_p8;
     static const int en = getenv("OCC_TN_P8") ? atoi(getenv("OCC_TN_P8")) : 1;
     static const int pair_en = getenv("OCC_TN_PAIR") ? atoi(getenv("OCC_TN_PAIR")) : 1;
@@ -320,7 +326,7 @@ int occ_tn_p8_pair_try(long long M, const long long* N1, const long long* N2, co
         a.N1 = N1[p]; a.N2 = N2[p]; a.A = (const char*)A[p]; a.amap = amap[p]; a.B = (const char*)B[p]; a.bmap = bmap[p]; a.C = C[p]; a.ldc = ldc[p]; a.alpha = alpha[p];
         a.t1 = (int)(N1[p] / 256); a.t2 = (int)(N2[p] / 256);
         a.nt = (int)(M / 64);
-        a.plain = 1;
+        a.plain = 1; a.store = store[p];
         tiles[p] = (long long)a.t1 * a.t2;
     }
     static int cus = 0;
@@ -335,14 +341,14 @@ int occ_tn_p8_pair_try(long long M, const long long* N1, const long long* N2, co
     ap.wgs0 = (int)(tiles[0] * S);
     hipLaunchKernelGGL(gemm_tn_p8_pair_kernel<true>, dim3((unsigned)(T * S)), dim3(512), 0, s, ap);
     hipLaunchKernelGGL(tn_p8_reduce_pair_kernel, dim3(64, (unsigned)T), dim3(256), 0, s, ap.v[0].slabs, ap.v[0].C, ap.v[0].ldc, ap.v[0].t1, (int)tiles[0], ap.v[1].slabs,
-                       ap.v[1].C, ap.v[1].ldc, ap.v[1].t1, ap.v[0].alpha, ap.v[1].alpha, (int)S);
+                       ap.v[1].C, ap.v[1].ldc, ap.v[1].t1, ap.v[0].alpha, ap.v[1].alpha, (int)S, store[0], store[1]);
     return 1;
 }
 
 // Host side.  Returns 1 when the launch was made, 0 when the problem is not this kernel's (the caller falls back), < 0 on error.
 // Covers rows [0, rows64) with rows64 = M - M % 64; the caller adds the last M % 64 rows with the small-tile kernel.
 int occ_tn_p8_try(long long M, long long N1, long long N2, const void* A, const RowMapI& amap, const void* B, const RowMapI& bmap, float* C, long long ldc,
-                  float alpha, void* workspace, long long workspace_bytes, long long max_a_off, long long max_b_off, hipStream_t s) {
+                  float alpha, void* workspace, long long workspace_bytes, long long max_a_off, long long max_b_off, int store, hipStream_t s) {
     using namespace occ_tn_p8;
     static const int en = getenv("OCC_TN_P8") ? atoi(getenv("OCC_TN_P8")) : 1;
     if (!en || N1 % 256 || N2 % 256 || M < 1024 || ldc % 4 || ((uintptr_t)C & 15)) return 0;
@@ -350,7 +356,7 @@ int occ_tn_p8_try(long long M, long long N1, long long N2, const void* A, const 
     Args a;
     a.N1 = N1; a.N2 = N2; a.A = (const char*)A; a.amap = amap; a.B = (const char*)B; a.bmap = bmap; a.C = C; a.ldc = ldc; a.alpha = alpha;
     a.t1 = (int)(N1 / 256); a.t2 = (int)(N2 / 256);
-    a.nt = (int)(M / 64);
+    a.nt = (int)(M / 64); a.store = store;
     a.plain = amap.rpl == 0 && bmap.rpl == 0 && amap.rpb >= M && bmap.rpb >= M;
     static int cus = 0;
     if (!cus) { int dev = 0, v = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }
@@ -366,6 +372,6 @@ int occ_tn_p8_try(long long M, long long N1, long long N2, const void* A, const 
     if (a.plain) hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, dim3((unsigned)(tiles * S)), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, dim3((unsigned)(tiles * S)), dim3(512), 0, s, a);
     if (S > 1)
-        hipLaunchKernelGGL(tn_p8_reduce_kernel, dim3(64, (unsigned)tiles), dim3(256), 0, s, a.slabs, a.C, a.ldc, a.alpha, a.S, a.t1);
+        hipLaunchKernelGGL(tn_p8_reduce_kernel, dim3(64, (unsigned)tiles), dim3(256), 0, s, a.slabs, a.C, a.ldc, a.alpha, a.S, a.t1, a.store);
     return 1;
 }

@@ -383,6 +383,7 @@ class XlsrFineTuner(XlsrFrontend):
             off += (nel + 7) // 8 * 8                   # 16-byte aligned slots in the bf16 mirror too (GEMM operands)
         self.P = torch.empty(off, device=self.device, dtype=torch.float32)
         self.G = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.grads_cleared = True
         # bf16 mirror of P: the forward GEMM operands are views into it; the optimizer writes it in the same pass as P (occ_adam_multi
         # bf16_copies), so no cast kernel re-reads the f32 masters every step
         self.Wb = torch.zeros(off, device=self.device, dtype=torch.bfloat16)
@@ -790,18 +791,20 @@ class XlsrFineTuner(XlsrFrontend):
     def zero_grad(self):
         from .. import backend_ops as K
         K.fill(self.G, 0.0)
+        self.grads_cleared = True            # until the next backward(): the weight-gradient kernels may store instead of accumulate
 
-    def _wgrad(self, dy, x, N, Kd, M, gname, bias_name):
+    def _wgrad(self, dy, x, N, Kd, M, gname, bias_name, c_is_zero=False):
         """G[gname] [N,Kd] += dy^T x ; G[bias] += colsum(dy).  dy [M,N], x [M,Kd], both bf16 as they lie in memory: occ_gemm_tn's
         LDS-DMA / transposing-read kernel needs no transposed copies."""
         from .. import backend_ops as K
         K.gemm_tn(M, N, Kd, dy, rowmap(M, 0, N), x, rowmap(M, 0, Kd), self.mg[gname], Kd, colsum_out=self.mg[bias_name], a_bf16=True, b_bf16=True,
-                  bf16_mfma=True)
+                  bf16_mfma=True, c_is_zero=c_is_zero)
 
     def _wgrad_pair(self, M, a, b):
         """Two weight (+ bias) gradients of one layer, (dy, x, N, Kd, gname, bias_name) each, in one launch (occ_gemm_tn_pair)."""
         from .. import backend_ops as K
-        K.gemm_tn_pair(M, *[(N, Kd, dy, rowmap(M, 0, N), x, rowmap(M, 0, Kd), self.mg[g], Kd, self.mg[bn] if bn is not None else None) for dy, x, N, Kd, g, bn in (a, b)])
+        K.gemm_tn_pair(M, *[(N, Kd, dy, rowmap(M, 0, N), x, rowmap(M, 0, Kd), self.mg[g], Kd, self.mg[bn] if bn is not None else None) for dy, x, N, Kd, g, bn in (a, b)],
+                       c_is_zero=self.grads_cleared)
 
     def layer_grad_range(self, i):
         """[lo, hi) of transformer layer i's gradients in the flat buffer self.G (its twelve tensors are contiguous)."""
@@ -885,6 +888,7 @@ class XlsrFineTuner(XlsrFrontend):
             self._drop_bwd("enc", dx, dx, p_res)
             self._drop_bwd("enc", dxb, dxb, p_res)
         self.ctx = None
+        self.grads_cleared = False           # a second backward() without zero_grad() accumulates
 
 
 class XlsrFullFineTuner(XlsrFineTuner):
@@ -1057,6 +1061,7 @@ class XlsrFullFineTuner(XlsrFineTuner):
 
     def backward(self, dfeats, grad_ready=None):
         B, L = self.ctx
+        cleared = self.grads_cleared                     # (every weight gradient below is written once per backward)
         super().backward(dfeats, grad_ready=grad_ready)  # leaves d(loss)/d(encoder input) in tr["dx"]
         from .. import backend_ops as K
         from .._lib import check, lib, ptr, stream_ptr
@@ -1090,7 +1095,7 @@ class XlsrFullFineTuner(XlsrFineTuner):
         if self._p("dropout_input") > 0:
             self._drop_bwd("in", dx, dx, self._p("dropout_input"))
         check(lib().occ_cast(ptr(dx), OCC_F32, ptr(tr["dxb"]), bfc, M * D, stream_ptr()), "occ_cast")      # dx changed since its bf16 copy was made
-        self._wgrad(tr["dxb"], cv["lnfeat"], D, 512, M, "proj.w", "proj.b")
+        self._wgrad(tr["dxb"], cv["lnfeat"], D, 512, M, "proj.w", "proj.b", c_is_zero=cleared)
         ops.gemm_raw(M, 512, D, dx, xm, self.wT["proj.w"], D, cv["dln"], rowmap(M, 0, 512), bfc, OCC_AF32_WBF16)
         ops.layernorm_bwd_ex(cv["dln"], cv["act"][6].view(M, 512), w["ln.g"], None, None, None, cv["dact"][6].view(M, 512), None, self.mg["ln.g"], self.mg["ln.b"], gelu=False)
         # fairseq scales the gradient that enters the conv feature extractor (GradMultiply, feature_grad_mult; 0 = extractor not trained)
@@ -1114,7 +1119,7 @@ class XlsrFullFineTuner(XlsrFineTuner):
             # (the k taps of a window are contiguous in the channels-last activation: the window IS the B row, row stride s*512)
             from .. import backend_ops as K
             K.gemm_tn(R, 512, k * 512, d_in, imap, cv["act"][i - 1], rowmap(Tout, Tin * 512, s * 512), self.mg["c%d.w" % i].view(512, k * 512), k * 512,
-                      colsum_out=self.mg["c%d.b" % i], a_bf16=True, b_bf16=True, bf16_mfma=True)
+                      colsum_out=self.mg["c%d.b" % i], a_bf16=True, b_bf16=True, bf16_mfma=True, c_is_zero=cleared)
             # input gradient
             dprev = cv["dact"][i - 1]
             if k == 3:

@@ -128,3 +128,24 @@ def test_grouped_conv_weight_gradient_in_one_launch_exact_integers(B, T, G, cg, 
     s = torch.zeros(D, device="cuda")
     K.colsum(dy_in, dmap, M, D, s, a_dtype=1)
     assert torch.equal(s.cpu().double(), dy[:, lo:lo + T].reshape(M, D).double().sum(0))
+
+
+@pytest.mark.parametrize("M,shapes", [(12736, ((1024, 1024), (3072, 1024))), (12736, ((1024, 4096), (4096, 1024))), (6368, ((1280, 1280), (3840, 1280)))])
+def test_tn_p8_c_is_zero_hint_stores_instead_of_accumulating(M, shapes):
+    """occ_gemm_tn_desc.c_is_zero: with C cleared the result is the product, exactly as with accumulation onto zeros; with a C that is NOT
+    zero the hinted call overwrites it (which shows the store path is the one that ran) while the plain call accumulates.  The bias sums
+    and the M % 64 tail rows, which are added after the slab reduce, are unaffected."""
+    from occm_amd import backend_ops as K
+    prods, ops_in = [], {}
+    for hint, c_init in ((True, 0.0), (False, 0.0), (True, 7.0)):
+        cur = []
+        for p, (N1, N2) in enumerate(shapes):
+            a, b = _ints(M, N1, 10 + p), _ints(M, N2, 20 + p)
+            C, s = torch.full((N1, N2), c_init, device="cuda"), torch.zeros(N1, device="cuda")
+            cur.append((N1, N2, a.bfloat16().cuda(), K.full(M, N1), b.bfloat16().cuda(), K.full(M, N2), C, N2, s))
+            if len(prods) <= p:
+                prods.append((a.double().T @ b.double(), a.double().sum(0)))
+        K.gemm_tn_pair(M, cur[0], cur[1], c_is_zero=hint)
+        for (N1, N2, _, _, _, _, C, _, s), (rc, rs) in zip(cur, prods):
+            assert torch.equal(C.cpu().double(), rc), (hint, c_init, float((C.cpu().double() - rc).abs().max()))
+            assert torch.equal(s.cpu().double(), rs)
