@@ -258,10 +258,12 @@ def pmc_traffic(tag):
             pm = json.load(open(path))
             if pm.get("workload") != tag or pm.get("gemm_src_sha16") != gemm_source_sha():
                 continue
-            ks = [v for k, v in pm["kernels"].items() if ("gemm_" in k and "bf16" in k) or "gemm_p8_kernel" in k or "gemm_tn_p8" in k or "gemm_tn_dma" in k]      # (GEMM kernels; not the slab reduce)
+            ks = [v for k, v in pm["kernels"].items() if ("gemm_" in k and "bf16" in k) or "gemm_p8_kernel" in k or "gemm_tn_p8" in k or "gemm_tn_dma" in k]
+            # the slab reduce that follows a weight-gradient kernel belongs to that launch: its bytes count, its launches do not
+            red = [v for k, v in pm["kernels"].items() if "tn_p8_reduce" in k]
             n = sum(v["launches"] for v in ks)
-            return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks) / max(n, 1)), \
-                "profiles/%s (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE, launch-weighted over the GEMM kernels)" % os.path.basename(path)
+            return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks + red) / max(n, 1)), \
+                "profiles/%s (separate --pmc passes of this command; 2*FETCH_SIZE + WRITE_SIZE, launch-weighted over the GEMM kernels, slab reduces included)" % os.path.basename(path)
         except (OSError, KeyError, ValueError):
             continue
     return None, "no PMC profile of this workload (%s) with these GEMM sources under profiles/" % tag
