@@ -27,7 +27,11 @@ enum occ_dtype { OCC_F32 = 0, OCC_BF16 = 1, OCC_F64 = 2, OCC_F32_AS_BF16 = 3 /* 
                  OCC_FP8_E4M3 = 5, OCC_FP8_E5M2 = 6 /* OCP 8-bit floats (e4m3fn / e5m2), one byte per element: occ_fp8_quantize output;
                     as occ_gemm ab_dtype: A in that format, W e4m3, products on v_mfma_scale_f32_16x16x128_f8f6f4, f32 accumulate */ };
 enum occ_act { OCC_ACT_NONE = 0, OCC_ACT_GELU = 1, OCC_ACT_SELU = 2, OCC_ACT_RELU = 3, OCC_ACT_TANH = 4,
-               OCC_ACT_GELU_GRAD = 5 /* occ_gemm epilogue: (acc+bias) * gelu'(aux) */ };
+               OCC_ACT_GELU_GRAD = 5 /* occ_gemm epilogue: (acc+bias) * gelu'(aux) */,
+               /* The same pair with the derivative computed ONCE, in the forward epilogue, where the exponential is already at hand:
+                * KEEP_GRAD: C = gelu(acc+bias), aux <- bf16(gelu'(acc+bias));  MUL_AUX: C = (acc+bias) * aux (no transcendental in the
+                * input-gradient epilogue, which is VALU-bound at N = 4096).                                                         */
+               OCC_ACT_GELU_KEEP_GRAD = 6, OCC_ACT_MUL_AUX = 7 };
 
 const char* occ_last_error(void);
 int occ_version(void);
@@ -146,7 +150,8 @@ typedef struct occ_gemm_desc {
      * output/bias/residual columns shifted by g*c_group_stride; n_groups <= 1 means a single problem. */
     int64_t n_groups, a_group_stride, w_group_stride, c_group_stride;
     /* optional bf16 side tensor addressed like C (same row map): with act = OCC_ACT_GELU the pre-activation (acc+bias) is
-     * stored to it (saved for backward); with act = OCC_ACT_GELU_GRAD it is read (the saved pre-activation).  NULL = unused. */
+     * stored to it (saved for backward); with act = OCC_ACT_GELU_GRAD it is read (the saved pre-activation); OCC_ACT_GELU_KEEP_GRAD
+     * stores gelu'(acc+bias) to it and OCC_ACT_MUL_AUX multiplies by it.  NULL = unused. */
     void* aux;
     /* fp8 operands (ab_dtype OCC_FP8_*): device scalars 1/scale of the per-tensor quantisation of A and W; the accumulator is
      * multiplied by alpha * (*a_dequant) * (*w_dequant) before bias.  NULL = 1.                                           */

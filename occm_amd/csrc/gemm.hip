@@ -584,6 +584,13 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     OCC_CHECK_ARG(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_F32 || d->ab_dtype == OCC_F32_AS_BF16 || d->ab_dtype == OCC_AF32_WBF16 || fp8,
                   "occ_gemm: ab_dtype must be bf16, f32, f32-as-bf16, af32-wbf16 or fp8 (e4m3 / e5m2)");
     OCC_CHECK_ARG(!(d->act == OCC_ACT_GELU_GRAD && !d->aux), "occ_gemm: OCC_ACT_GELU_GRAD needs aux");
+    if (d->act == OCC_ACT_GELU_KEEP_GRAD || d->act == OCC_ACT_MUL_AUX) {
+        OCC_CHECK_ARG(d->aux && d->c_dtype == OCC_BF16 && !d->R && d->alpha == 1.0f, "occ_gemm: OCC_ACT_GELU_KEEP_GRAD / OCC_ACT_MUL_AUX need aux, a bf16 C, no residual, alpha = 1");
+        if (!(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_FP8_E4M3 || d->ab_dtype == OCC_FP8_E5M2)) {
+            occ_set_error("occ_gemm: OCC_ACT_GELU_KEEP_GRAD / OCC_ACT_MUL_AUX exist in the bf16 / fp8 kernels' epilogues only (ab_dtype %d)", d->ab_dtype);
+            return OCC_EUNSUPPORTED;
+        }
+    }
     OCC_CHECK_ARG(d->c_dtype == OCC_BF16 || d->c_dtype == OCC_F32, "occ_gemm: c_dtype must be bf16 or f32");
     OCC_CHECK_ARG(!d->R || d->r_dtype == OCC_BF16 || d->r_dtype == OCC_F32, "occ_gemm: r_dtype must be bf16 or f32");
     const int ce = d->ab_dtype == OCC_F32 ? 4 : (fp8 ? 16 : 8);            // K granularity: one 16-byte LDS chunk

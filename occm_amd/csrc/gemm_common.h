@@ -39,7 +39,7 @@ struct GemmArgs {
 
 __device__ __forceinline__ float act_rt(int act, float v) {
     switch (act) {
-        case OCC_ACT_GELU: return gelu_erf(v);
+        case OCC_ACT_GELU: case OCC_ACT_GELU_KEEP_GRAD: return gelu_erf(v);
         case OCC_ACT_SELU: return selu_f(v);
         case OCC_ACT_RELU: return v > 0.f ? v : 0.f;
         case OCC_ACT_TANH: return tanhf(v);
@@ -53,7 +53,8 @@ __device__ __forceinline__ float act_rt(int act, float v) {
 // with run-time switches; on the 128x128 tile that code executed ~1500 instructions per thread, which (with the workgroups of a
 // round reaching it together) was a third of a K = 1024 GEMM's run time.
 // AUXM: 0 no side tensor; 1 store the bf16 pre-activation (acc + bias) to aux (forward of fc1, kept for backward); 2 multiply by
-// GELU'(aux) (the input gradient through fc1's activation).
+// GELU'(aux) (the input gradient through fc1's activation); 3 store bf16 gelu'(acc + bias) to aux and apply GELU (GELU must be false: the
+// pair comes from one exponential); 4 multiply by aux as it is.
 template <int NJ, bool HASB, bool GELU, bool HASR, bool CBF, int AUXM = 0>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&acc)[4][NJ], long long mrow0, long long ncol0, int fr, int fq, long long cshift,
                                                    const f32x4* breg, long long mlim) {
@@ -88,6 +89,19 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
                 const uint2 u = *reinterpret_cast<const uint2*>(a.aux + coff + n);
                 v[0] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x & 0xffff))); v[1] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x >> 16)));
                 v[2] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y & 0xffff))); v[3] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y >> 16)));
+            }
+            if (AUXM == 3) {
+                float gq[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float y; gelu_fwd_grad(v[e], y, gq[e]); v[e] = y; }
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(gq[0]) | ((unsigned)f32_to_bf16_bits(gq[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(gq[2]) | ((unsigned)f32_to_bf16_bits(gq[3]) << 16);
+                *reinterpret_cast<uint2*>(a.aux + coff + n) = o;
+            }
+            if (AUXM == 4) {
+                const uint2 u = *reinterpret_cast<const uint2*>(a.aux + coff + n);
+                v[0] *= __uint_as_float(u.x << 16); v[1] *= __uint_as_float(u.x & 0xffff0000u); v[2] *= __uint_as_float(u.y << 16); v[3] *= __uint_as_float(u.y & 0xffff0000u);
             }
             if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
             if (HASR) v += *reinterpret_cast<const f32x4*>(a.R + (roff + n) * 4);
@@ -134,6 +148,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
     if (a.alpha == 1.0f && a.aux && !a.R && a.c_dtype != OCC_F32) {
         if (a.act == OCC_ACT_GELU && a.bias) { gemm_epilogue_fast<NJ, true, true, false, true, 1>(a, acc, mrow0, ncol0, fr, fq, cshift, breg, mlim); return; }
         if (a.act == OCC_ACT_GELU_GRAD && !a.bias) { gemm_epilogue_fast<NJ, false, false, false, true, 2>(a, acc, mrow0, ncol0, fr, fq, cshift, breg, mlim); return; }
+        if (a.act == OCC_ACT_GELU_KEEP_GRAD && a.bias) { gemm_epilogue_fast<NJ, true, false, false, true, 3>(a, acc, mrow0, ncol0, fr, fq, cshift, breg, mlim); return; }
+        if (a.act == OCC_ACT_MUL_AUX && !a.bias) { gemm_epilogue_fast<NJ, false, false, false, true, 4>(a, acc, mrow0, ncol0, fr, fq, cshift, breg, mlim); return; }
     }
     if (a.alpha == 1.0f && !a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU) && (!a.R || a.r_dtype == OCC_F32)) {
         // wave-uniform flags -> one scalar branch chain into a straight-line instantiation
@@ -178,6 +194,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
                 const uint2 u = *reinterpret_cast<const uint2*>(a.aux + coff + n);
                 v[0] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x & 0xffff))); v[1] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x >> 16)));
                 v[2] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y & 0xffff))); v[3] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y >> 16)));
+            } else if (a.act == OCC_ACT_MUL_AUX) {
+                const uint2 u = *reinterpret_cast<const uint2*>(a.aux + coff + n);
+                v[0] *= __uint_as_float(u.x << 16); v[1] *= __uint_as_float(u.x & 0xffff0000u); v[2] *= __uint_as_float(u.y << 16); v[3] *= __uint_as_float(u.y & 0xffff0000u);
+            } else if (a.act == OCC_ACT_GELU_KEEP_GRAD) {
+                float gq[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float y; gelu_fwd_grad(v[e], y, gq[e]); v[e] = y; }
+                if (a.aux) {
+                    uint2 o;
+                    o.x = (unsigned)f32_to_bf16_bits(gq[0]) | ((unsigned)f32_to_bf16_bits(gq[1]) << 16);
+                    o.y = (unsigned)f32_to_bf16_bits(gq[2]) | ((unsigned)f32_to_bf16_bits(gq[3]) << 16);
+                    *reinterpret_cast<uint2*>(a.aux + coff + n) = o;
+                }
             } else if (a.act != OCC_ACT_NONE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_rt(a.act, v[e]);
@@ -241,7 +270,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
             long long m = mrow0 + ch * 32 + k * 8 + rr; if (m > a.M - 1) m = a.M - 1;
             return *reinterpret_cast<const uint4*>(a.aux + (plain_c ? m * a.cmap.rstride : row_off(a.cmap, m)) + nld);
         };
-        if (AUXM == 2 && a.N >= 8) {
+        if ((AUXM == 2 || AUXM == 4) && a.N >= 8) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ux[k] = load_aux(0, k);
         }
@@ -258,7 +287,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(lds_wave + rloc * RS + cc * 32), v1 = *reinterpret_cast<const f32x4*>(lds_wave + rloc * RS + cc * 32 + 16);
                 const long long m = mrow0 + ch * 32 + rloc;
                 uint4 u = make_uint4(0, 0, 0, 0);
-                if (AUXM == 2 && a.N >= 8) { u = ux[k]; if (ch + 1 < NCH) ux[k] = load_aux(ch + 1, k); }
+                if ((AUXM == 2 || AUXM == 4) && a.N >= 8) { u = ux[k]; if (ch + 1 < NCH) ux[k] = load_aux(ch + 1, k); }
                 if (m >= a.M || n >= a.N || ch * 32 + rloc >= rows) continue;
                 const long long coff = (plain_c ? m * a.cmap.rstride : row_off(a.cmap, m)) + n;
                 v0 = v0 * al; v1 = v1 * al;
@@ -278,6 +307,22 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
                     const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[2 * e] *= gelu_grad(bf16_bits_to_f32((unsigned short)(w[e] & 0xffff))); v[2 * e + 1] *= gelu_grad(bf16_bits_to_f32((unsigned short)(w[e] >> 16))); }
+                }
+                if (AUXM == 3) {                    // gelu and gelu' from one exponential; the derivative (bf16) is what backward multiplies by
+                    float gq[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { float y; gelu_fwd_grad(v[e], y, gq[e]); v[e] = y; }
+                    uint4 og;
+                    og.x = (unsigned)f32_to_bf16_bits(gq[0]) | ((unsigned)f32_to_bf16_bits(gq[1]) << 16); og.y = (unsigned)f32_to_bf16_bits(gq[2]) | ((unsigned)f32_to_bf16_bits(gq[3]) << 16);
+                    og.z = (unsigned)f32_to_bf16_bits(gq[4]) | ((unsigned)f32_to_bf16_bits(gq[5]) << 16); og.w = (unsigned)f32_to_bf16_bits(gq[6]) | ((unsigned)f32_to_bf16_bits(gq[7]) << 16);
+                    if (whole) *reinterpret_cast<uint4*>(a.aux + coff) = og;
+                    else *reinterpret_cast<uint2*>(a.aux + coff) = make_uint2(og.x, og.y);
+                }
+                if (AUXM == 4) {
+                    if (!whole) { const uint2 t = *reinterpret_cast<const uint2*>(a.aux + coff); u = make_uint4(t.x, t.y, 0, 0); }
+                    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[2 * e] *= __uint_as_float(w[e] << 16); v[2 * e + 1] *= __uint_as_float(w[e] & 0xffff0000u); }
                 }
                 if (GELU) {
 #pragma unroll
@@ -370,6 +415,19 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
                 v[0] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x & 0xffff))); v[1] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.x >> 16)));
                 v[2] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y & 0xffff))); v[3] *= gelu_grad(bf16_bits_to_f32((unsigned short)(u.y >> 16)));
             }
+            if (AUXM == 3) {
+                float gq[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float y; gelu_fwd_grad(v[e], y, gq[e]); v[e] = y; }
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(gq[0]) | ((unsigned)f32_to_bf16_bits(gq[1]) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(gq[2]) | ((unsigned)f32_to_bf16_bits(gq[3]) << 16);
+                *reinterpret_cast<uint2*>(a.aux + coff) = o;
+            }
+            if (AUXM == 4) {
+                const uint2 u = *reinterpret_cast<const uint2*>(a.aux + coff);
+                v[0] *= __uint_as_float(u.x << 16); v[1] *= __uint_as_float(u.x & 0xffff0000u); v[2] *= __uint_as_float(u.y << 16); v[3] *= __uint_as_float(u.y & 0xffff0000u);
+            }
             if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
             if (HASR) v += rv;
             if (CBF) {
@@ -390,7 +448,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
 // NJ * 16 are stored (the 224-row tile passes 112) -- honoured by the row-layout forms only, see rows_epilogue_applies.
 __host__ __device__ inline bool rows_epilogue_applies(const GemmArgs& a) {
     if (a.R && a.r_dtype != OCC_F32) return false;
-    if (a.aux) return !a.R && a.c_dtype != OCC_F32 && ((a.act == OCC_ACT_GELU && a.bias) || (a.act == OCC_ACT_GELU_GRAD && !a.bias));
+    if (a.aux) return !a.R && a.c_dtype != OCC_F32 && (((a.act == OCC_ACT_GELU || a.act == OCC_ACT_GELU_KEEP_GRAD) && a.bias) || ((a.act == OCC_ACT_GELU_GRAD || a.act == OCC_ACT_MUL_AUX) && !a.bias));
     return a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU;
 }
 template <int NJ>
@@ -401,6 +459,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& a, f32x4 (&ac
         if (a.aux && !a.R && a.c_dtype != OCC_F32) {
             if (a.act == OCC_ACT_GELU && a.bias) { gemm_epilogue_rows_t<NJ, true, true, false, true, 1>(a, acc, mrow0, ncol0, lane, lds_wave, rows, part_row); return; }
             if (a.act == OCC_ACT_GELU_GRAD && !a.bias) { gemm_epilogue_rows_t<NJ, false, false, false, true, 2>(a, acc, mrow0, ncol0, lane, lds_wave, rows, part_row); return; }
+            if (a.act == OCC_ACT_GELU_KEEP_GRAD && a.bias) { gemm_epilogue_rows_t<NJ, true, false, false, true, 3>(a, acc, mrow0, ncol0, lane, lds_wave, rows, part_row); return; }
+            if (a.act == OCC_ACT_MUL_AUX && !a.bias) { gemm_epilogue_rows_t<NJ, false, false, false, true, 4>(a, acc, mrow0, ncol0, lane, lds_wave, rows, part_row); return; }
         }
         if (!a.aux && (a.act == OCC_ACT_NONE || a.act == OCC_ACT_GELU)) {
             const int key = (a.bias ? 8 : 0) | (a.act == OCC_ACT_GELU ? 4 : 0) | (a.R ? 2 : 0) | (a.c_dtype != OCC_F32 ? 1 : 0);

@@ -102,6 +102,20 @@ __device__ __forceinline__ float gelu_grad(float x) {
     const float cdf = 0.5f * (1.0f + copysignf(fmaf(-p, e, 1.0f), x));
     return fmaf(x, 0.39894228040143267794f * e, cdf);
 }
+// gelu(x) and gelu'(x) from one exponential and one reciprocal (the forward epilogue that also leaves gelu' for the backward pass)
+__device__ __forceinline__ void gelu_fwd_grad(float x, float& y, float& dy) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+    const float cdf = 0.5f * (1.0f + copysignf(fmaf(-p, e, 1.0f), x));
+    y = x * cdf;
+    dy = fmaf(x, 0.39894228040143267794f * e, cdf);
+}
 __device__ __forceinline__ float selu_f(float x) {
     const float a = 1.6732632423543772848170429916717f, s = 1.0507009873554804934193349852946f;
     return x > 0.f ? s * x : s * a * (expf(x) - 1.0f);

@@ -12,13 +12,19 @@ contiguous K-segment of the implicit GEMM); the residual stream is f32, GEMM ope
 for the parity path); the projection output is written into a zero-padded ``[B, T+128, D]`` buffer that
 the grouped positional conv reads as 128 K-segments.
 """
+import os
+
 import torch
 
 from .. import ops
-from .._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, OCC_AF32_WBF16, OCC_BF16 as OCC_BF16_CODE, OCC_F32, OccError, dtype_code, require_gpu
+from .._lib import ACT_GELU, ACT_GELU_GRAD, ACT_GELU_KEEP_GRAD, ACT_MUL_AUX, ACT_NONE, OCC_AF32_WBF16, OCC_BF16 as OCC_BF16_CODE, OCC_F32, OccError, dtype_code, require_gpu
 from ..ops import rowmap
 
 WS_CACHE = 12            # activation workspaces kept per model (one per distinct input shape)
+# fc1's forward epilogue leaves bf16 gelu'(pre-activation) for backward (one exponential serves gelu and gelu') and fc2's input-gradient
+# epilogue multiplies by it, instead of saving the pre-activation and evaluating gelu' there.  OCC_GELU_KEEP_GRAD=0: the older pair.
+KEEP_GELU_GRAD = os.environ.get("OCC_GELU_KEEP_GRAD", "1") != "0"
+
 CONV_LAYERS = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2     # fairseq conv_feature_layers of XLS-R
 
 
@@ -743,7 +749,7 @@ class XlsrFineTuner(XlsrFrontend):
             else:
                 self._lin(i, "o.w", s["att"], "att", M, D, D, x_mid, xmap, OCC_F32, bias=w["l%d.o.b" % i], R=x_in, r_map=xmap, r_dtype=OCC_F32)
             self._ln_fwd(i, x_mid, "ln2", s["h2"], "h2")
-            self._lin(i, "fc1.w", s["h2"], "h2", M, Fd, D, s["f"], rowmap(M, 0, Fd), code, bias=w["l%d.fc1.b" % i], act=ACT_GELU, aux=s["u"],
+            self._lin(i, "fc1.w", s["h2"], "h2", M, Fd, D, s["f"], rowmap(M, 0, Fd), code, bias=w["l%d.fc1.b" % i], act=ACT_GELU_KEEP_GRAD if KEEP_GELU_GRAD else ACT_GELU, aux=s["u"],
                       f8_next="f" if p_act == 0 else None)
             if p_act > 0:                                        # dropout2 on the activation
                 self._drop_fwd("l%d.act" % i, s["f"], s["f"], p_act)
@@ -851,7 +857,7 @@ class XlsrFineTuner(XlsrFrontend):
                 dyb = tr["dyb"]; self._drop_bwd("l%d.d3" % i, dxb, dyb, p_res)
             # fc1's bias gradient = column sums of du: from the same epilogue that writes du (large launches, no activation dropout on du)
             fc1_bias_fused = p_act == 0 and M * Fd >= 180 * 65536 and Fd % 8 == 0 and D % 64 == 0
-            self._dgrad(i, "fc2.w", dyb, "g_fc2", M, Fd, D, tr["du"], act=ACT_GELU_GRAD, aux=s["u"], f8_next="g_fc1" if p_act == 0 else None,
+            self._dgrad(i, "fc2.w", dyb, "g_fc2", M, Fd, D, tr["du"], act=ACT_MUL_AUX if KEEP_GELU_GRAD else ACT_GELU_GRAD, aux=s["u"], f8_next="g_fc1" if p_act == 0 else None,
                         colsum=self.mg["l%d.fc1.b" % i] if fc1_bias_fused else None)
             if p_act > 0:                                        # (elementwise factors commute: mask after GELU')
                 self._drop_bwd("l%d.act" % i, tr["du"], tr["du"], p_act)

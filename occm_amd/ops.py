@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_GELU_GRAD, ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, OCC_AF32_WBF16, OCC_BF16, OCC_F32, OCC_F32_AS_BF16, OCC_F64,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_GELU_GRAD, ACT_GELU_KEEP_GRAD, ACT_MUL_AUX, ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, OCC_AF32_WBF16, OCC_BF16, OCC_F32, OCC_F32_AS_BF16, OCC_F64,  # noqa: F401
                    GemmDesc, RowMap, check, dtype_code, lib, ptr, stream_ptr)
 
 

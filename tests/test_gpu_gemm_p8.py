@@ -197,3 +197,32 @@ def test_gelu_grad_epilogue_also_gives_the_column_sums(M, N, K):
     cs2 = torch.full((N,), 0.5, device="cuda")
     run(C1, c_colsum=cs2)
     assert torch.equal(cs2, cs)
+
+
+@pytest.mark.parametrize("force", [30, 0])                    # the eight-phase kernel's row epilogue, then whatever the dispatcher picks for the shape
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 256), (448, 260, 128), (12736, 4096, 1024)])
+def test_gelu_keep_grad_and_mul_aux_epilogues(M, N, K, force):
+    """OCC_ACT_GELU_KEEP_GRAD: C = gelu(x W^T + b), aux = bf16(gelu'(x W^T + b)) (one exponential for both); OCC_ACT_MUL_AUX: C = (dy W2) * aux.
+    Against f64 torch on the same bf16 operands: both outputs are bf16 roundings of the exact values up to the 1.5e-7 of the erf approximation."""
+    from occm_amd import ops
+    from occm_amd._lib import lib
+    if force == 0:
+        lib().occ_gemm_variant(1)
+    g = torch.Generator().manual_seed(M + N)
+    x = (0.5 * torch.randn(M, K, generator=g)).bfloat16(); w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16(); b = 0.3 * torch.randn(N, generator=g)
+    pre = (x.double() @ w.double().T + b.double())
+    pre.requires_grad_(True)
+    y = torch.nn.functional.gelu(pre)
+    y.sum().backward()
+    C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"); aux = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    cmap = ops.rowmap(M, 0, N)
+    ops.gemm_raw(M, N, K, x.cuda(), ops.rowmap(M, 0, K), w.cuda(), K, C, cmap, ops.OCC_BF16, ops.OCC_BF16, bias=b.cuda(), act=ops.ACT_GELU_KEEP_GRAD, aux=aux)
+    ey = (C.cpu().double() - y.detach()).abs(); eg = (aux.cpu().double() - pre.grad).abs()
+    assert float((ey / (y.detach().abs() + 1e-2)).max()) < 6e-3 and float((eg / (pre.grad.abs() + 1e-2)).max()) < 6e-3, (float(ey.max()), float(eg.max()))
+    # backward form: du = (dy W2^T-operand) * aux, with aux the tensor just written
+    dy = (0.5 * torch.randn(M, K, generator=g)).bfloat16(); w2t = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    du = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_raw(M, N, K, dy.cuda(), ops.rowmap(M, 0, K), w2t.cuda(), K, du, cmap, ops.OCC_BF16, ops.OCC_BF16, act=ops.ACT_MUL_AUX, aux=aux)
+    ref = (dy.double() @ w2t.double().T) * aux.cpu().double()
+    err = (du.cpu().double() - ref).abs()
+    assert float((err / (ref.abs() + 1e-2)).max()) < 6e-3, float(err.max())
