@@ -1,6 +1,6 @@
 """Training soak (scripts/soak_train.py) as a test: 160 optimizer steps of the configs[2] step (XLS-R-300M fine-tuned end to end + AASIST,
 RawBoost 5, bf16) at bs 24 on a synthetic task with a learnable signal and fresh waveforms every step, in a child process.  The
-descriptiveness loss of the last tenth must be below 0.8x the first tenth's (measured at bs 48 / 240 steps: 1.34 -> 0.24, fp8 1.15 -> 0.18,
+descriptiveness loss of the last tenth must be below 0.8x the first tenth's (measured at bs 48 / 1000 steps: 0.76 -> 0.048, fp8 0.67 -> 0.055,
 profiles/r03_soak_train*.json), every loss finite, and the allocator's high-water mark after 20 steps is the one at the end."""
 import json
 import os
