@@ -220,8 +220,9 @@ def main(argv=None):
     parser.add_argument("--num_workers", type=int, default=0)
     parser.add_argument("--ssl_dtype", choices=["f32", "bf16"], default="f32",
                         help="arithmetic of the XLS-R front-end and the AASIST GEMMs: f32 (default) = exact-f32 MFMA, the path that meets the 1e-3 "
-                             "parity bar against the reference's fp32; bf16 = bf16 MFMA with f32 accumulate, ~8x the throughput, embeddings off by ~1e-2 "
-                             "(DESIGN.md section 5 states the measured effect on distances and EER)")
+                             "parity bar against the reference's fp32 (embeddings within 2e-5 of the CPU oracle on the 24-layer model); bf16 = bf16 "
+                             "MFMA with f32 accumulate, the training arithmetic: faster, but on the 24-layer model embeddings move by up to ~2.5 and "
+                             "distances by up to ~1 (DESIGN.md section 5, profiles/r03_scoring_parity_300m.json)")
     args = parser.parse_args(argv)
     from .models.sslassist import AModel
     from . import parallel
