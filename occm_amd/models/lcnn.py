@@ -16,6 +16,7 @@ import torch
 from .. import backend_ops as K
 from .. import ops
 from .._lib import ACT_NONE, OCC_F32, OCC_F32_AS_BF16, OccError, check, lib, ptr, require_gpu, stream_ptr
+from ..autograd_bridge import AliasGuard, attach_parameters, run_engine
 from ..ops import rowmap
 
 C_S = [128, 64, 32, 16, 8, 4, 2]            # lcnn.py:153
@@ -109,6 +110,17 @@ class LcnnBackend:
                     self.p[name].zero_(); self.p[name][..., : shp[1]].copy_(v.float().permute(0, 2, 3, 1))
                 else:
                     self.p[name].copy_(v.float().reshape(self.p[name].shape))
+
+    def ref_views(self, flat):
+        """{reference name: VIEW of ``flat`` (self.P / self.G / same-sized buffer) in the reference's shape}."""
+        out = {}
+        for name, shp, kind in self.table:
+            if kind == "buf":
+                continue
+            o, ishp, n = self.slots[name]
+            v = flat[o:o + n].view(ishp)
+            out[name] = v[..., : shp[1]].permute(0, 3, 1, 2) if kind == "conv" else v.view(shp)
+        return out
 
     def _export(self, src):
         out = {}
@@ -404,17 +416,28 @@ def synthetic_lcnn_params(seed=4):
     return out
 
 
-class _Lcnn(torch.nn.Module):
-    """Module facade with the reference's call signature (lcnn.py:186: ``forward(x, eval=False)``)."""
+class _Lcnn(AliasGuard, torch.nn.Module):
+    """Module facade with the reference's call signature (lcnn.py:186: ``forward(x, eval=False)``); parameters and autograd as
+    ``models.senet._SeResNet``."""
 
     def __init__(self, state_dict=None, device="cuda", seed=4, compute="f32", asoftmax=False, **kwargs):
         super().__init__()
         if asoftmax:
             raise OccError("the A-softmax head (lcnn.py:22-119) is not on the path: the reference builds lcnn_net(asoftmax=False) only")
         self.backend = LcnnBackend(state_dict, device=device, seed=seed, compute=compute)
+        self.param_set = attach_parameters(self, self.backend)
 
     def forward(self, x, eval=False, masks=None):
-        return self.backend.forward(x, train=self.training, masks=masks)
+        be = self.backend
+        if not self.training:
+            with torch.no_grad():
+                return be.forward(x, train=False, masks=masks)
+
+        def bwd(grads, needs):
+            d = be.backward(grads[0].contiguous().float(), want_dfeats=bool(needs[0]))
+            return (d.view(x.shape) if needs[0] else None,)
+
+        return run_engine(self.param_set, lambda t: be.forward(t, train=True, masks=masks), bwd, x)
 
     def backward(self, dlogits, want_dfeats=False):
         return self.backend.backward(dlogits, want_dfeats=want_dfeats)
@@ -454,7 +477,7 @@ class ssl_lcnn(torch.nn.Module):
         self.backend = self.lcnn.backend
 
     def forward(self, x):
-        feats = self.frontend.model.forward(x, out_dtype=torch.float32)
+        feats = self.frontend.extract_feat(x)
         self.lcnn.train(self.training)
         return self.lcnn(feats.unsqueeze(1))
 

@@ -31,7 +31,7 @@ class OCCM(torch.nn.Module):
 
     def forward(self, x, masks=None):
         """x f32 [B,L] waveforms -> (senet34_output, lcnn_output) as occm.py:55-67."""
-        return self.forward_features(self.frontend.model.forward(x, out_dtype=torch.float32), masks=masks)
+        return self.forward_features(self.frontend.extract_feat(x), masks=masks)
 
     def backward(self, dcom, ddes, dlcnn, want_dfeats=False):
         """Parameter gradients of both branches; with want_dfeats the summed gradient wrt the shared features [B,T,1024]."""

@@ -15,6 +15,7 @@ import torch
 from .. import backend_ops as K
 from .. import ops
 from .._lib import ACT_NONE, ACT_RELU, OCC_F32, OCC_F32_AS_BF16, OccError, check, lib, ptr, require_gpu, stream_ptr
+from ..autograd_bridge import AliasGuard, attach_parameters, run_engine
 from ..ops import rowmap
 
 LAYERS = [3, 4, 6, 3]                       # senet.py:154-156
@@ -120,6 +121,16 @@ class SeResNet34Backend:
             for k in self.buf:
                 if k in sd:
                     self.buf[k].copy_(sd[k].to(self.device).reshape(self.buf[k].shape))
+
+    def ref_views(self, flat):
+        """{reference name: VIEW of ``flat`` (self.P / self.G / same-sized buffer) in the reference's shape} (conv weights are
+        channels-last and channel-padded inside)."""
+        out = {}
+        for name, shp in self.table:
+            o, ishp, n = self.slots[name]
+            v = flat[o:o + n].view(ishp)
+            out[name] = v[..., : shp[1]].permute(0, 3, 1, 2) if len(shp) == 4 and shp[2:] != (1, 1) else v.view(shp)
+        return out
 
     def _export(self, src):
         out = {}
@@ -463,15 +474,33 @@ def synthetic_senet_params(seed=1):
     return out
 
 
-class _SeResNet(torch.nn.Module):
-    """Module facade with the reference's call signature (senet.py:120-142)."""
+class _SeResNet(AliasGuard, torch.nn.Module):
+    """Module facade with the reference's call signature (senet.py:120-142).  Every reference tensor is a registered nn.Parameter
+    (reference name and shape, a view of the engine's flat buffer) and a training-mode forward is taped through
+    ``autograd_bridge.EngineFunction``: ``optim.Adam(m.parameters())`` / ``loss.backward()`` / ``optimizer.step()`` of
+    test_dataloader_v2.py:69, 119-130 drive the HIP kernels."""
 
     def __init__(self, state_dict=None, device="cuda", seed=1, compute="f32", **kwargs):
         super().__init__()
         self.backend = SeResNet34Backend(state_dict, device=device, seed=seed, compute=compute)
+        self.param_set = attach_parameters(self, self.backend)
 
     def forward(self, x, eval=False):
-        return self.backend.forward(x, train=self.training)
+        be = self.backend
+        if not self.training:
+            with torch.no_grad():
+                return be.forward(x, train=False)
+
+        def bwd(grads, needs):
+            dcom, ddes = (None if g is None else g.contiguous().float() for g in grads)
+            if dcom is None:
+                dcom = torch.zeros(x.shape[0], 128, device=be.device)
+            if ddes is None:
+                ddes = torch.zeros(x.shape[0], 2, device=be.device)
+            d = be.backward(dcom, ddes, want_dfeats=bool(needs[0]))
+            return (d.view(x.shape) if needs[0] else None,)
+
+        return run_engine(self.param_set, lambda t: be.forward(t, train=True), bwd, x)
 
     def backward(self, dcom, ddes, want_dfeats=False):
         return self.backend.backward(dcom, ddes, want_dfeats=want_dfeats)
@@ -512,7 +541,7 @@ class ssl_resnet34(torch.nn.Module):
         self.backend = self.resnet34.backend
 
     def forward(self, x):
-        feats = self.frontend.model.forward(x, out_dtype=torch.float32)
+        feats = self.frontend.extract_feat(x)
         self.resnet34.train(self.training)
         return self.resnet34(feats.unsqueeze(1))
 

@@ -20,6 +20,7 @@ import torch
 from .. import backend_ops as K
 from .. import ops
 from .._lib import ACT_NONE, ACT_SELU, ACT_TANH, OCC_F32, OCC_F32_AS_BF16, OccError, require_gpu
+from ..autograd_bridge import AliasGuard, attach_parameters, run_engine
 from ..ops import rowmap
 from . import xlsr as xlsr_mod
 
@@ -198,6 +199,20 @@ class AasistBackend:
                 out[name] = self.p[name].detach().clone().reshape(shp)
         for k, v in self.buf.items():
             out[k] = v.clone().reshape(()) if k.endswith("num_batches_tracked") else v.clone()
+        return out
+
+    def ref_views(self, flat):
+        """{reference name: VIEW of ``flat`` (self.P, self.G or a buffer of the same size) in the reference's shape}: conv weights are
+        channels-last (and channel-padded) inside, the three typed attention weights of a layer are rows of one [3, Do] slot."""
+        out = {}
+        for name, shp in self.table:
+            leaf = name.rsplit(".", 1)[-1]
+            if leaf in _AW_ROW:
+                out[name] = self._view(flat, name.rsplit(".", 1)[0] + ".aw3")[_AW_ROW[leaf]].view(shp)
+            elif len(shp) == 4 and shp[2:] != (1, 1):
+                out[name] = self._view(flat, name)[..., : shp[1]].permute(0, 3, 1, 2)
+            else:
+                out[name] = self._view(flat, name).view(shp)
         return out
 
     def grad_dict(self):
@@ -694,29 +709,56 @@ def synthetic_backend_params(seed=0):
 
 class SSLModel(xlsr_mod.SSLModel):
     """sslassist.py:20-49 -- same wrapper as models/xlsr.py but WITHOUT the eval() call (quirk 10)."""
+    _eval_at_init = False
 
 
-class AModel(torch.nn.Module):
+class AModel(AliasGuard, torch.nn.Module):
     """Mirror of sslassist.AModel (:432-597): ``AModel(args, device)``; ``forward(x[B,L] or [B,L,1])``.
+
+    Trainable the way the reference trains it (oc_training.py:320-328, 363-385): every back-end tensor is a registered ``nn.Parameter``
+    under the reference's name and shape (``LL.weight``, ``encoder.0.0.conv1.weight`` [32,1,2,3], ``GAT_layer_S.att_weight`` ...), a view
+    of the engine's flat f32 buffer; with ``finetune_ssl=True`` so are XLS-R's (``ssl_model.model.<fairseq name>``).  A training-mode
+    forward is taped through ``autograd_bridge.EngineFunction`` (front-end and back-end each), so ``optim.Adam(aasist.parameters())``,
+    ``loss.backward()`` and ``optimizer.step()`` drive the HIP forward / backward kernels; ``occm_amd.trainer.OcTrainer`` is the fused
+    fast path over the same engines.  ``nn.DataParallel(aasist)`` works as a pass-through on one visible GPU; multi-GPU data parallelism
+    is one process per GPU (``bench.py --gpus N`` / ``occm_amd.parallel``), not replica threads.
 
     Extra keyword arguments (not in the reference): ``ssl_cfg`` / ``ssl_dtype`` / ``ssl_state_dict`` choose the
     XLS-R variant, compute dtype and weights; ``backend_state_dict`` the AASIST weights; both fall back to the
     deterministic synthetic filler because no checkpoint exists offline (the reference hard-codes a path, :24)."""
 
     def __init__(self, args=None, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, backend_state_dict=None, seed=0,
-                 backend_compute=None, finetune_ssl=False, ssl_cp_path=None, synthetic_ssl=False, ssl_train_cfg=None):
+                 backend_compute=None, finetune_ssl=False, ssl_cp_path=None, synthetic_ssl=False, ssl_train_cfg=None, ssl_model=None):
+        """ssl_model: a ready front-end module offering ``extract_feat(x) -> f32 [B,T,1024]`` to use instead of building ``SSLModel``
+        (the parity tests pass a stub that hands seeded features through, exactly as the golden generator stubs the reference's)."""
         super().__init__()
         self.device = device
-        self.ssl_model = SSLModel(device, cp_path=ssl_cp_path, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, seed=seed, finetune=finetune_ssl,
-                                  synthetic=synthetic_ssl, train_cfg=ssl_train_cfg)
+        self.ssl_model = ssl_model if ssl_model is not None else \
+            SSLModel(device, cp_path=ssl_cp_path, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, seed=seed, finetune=finetune_ssl,
+                     synthetic=synthetic_ssl, train_cfg=ssl_train_cfg)
         if backend_compute is None:
             backend_compute = "bf16" if ssl_dtype == torch.bfloat16 else "f32"
         self.backend = AasistBackend(backend_state_dict, device=device, seed=seed, compute=backend_compute)
+        self.param_set = attach_parameters(self, self.backend)
+        self.dropout_masks = None      # None: draw masks on the device; {}: every back-end dropout off (the p = 0 of a parity run)
 
     def forward(self, x, masks=None):
         x = x.squeeze(-1) if x.dim() == 3 else x
-        feats = self.ssl_model.model.forward(x, out_dtype=torch.float32)
-        return self.backend.forward(feats, train=self.training, masks=masks)
+        feats = self.ssl_model.extract_feat(x)
+        masks = self.dropout_masks if masks is None else masks
+        be = self.backend
+        if not self.training:
+            with torch.no_grad():
+                return be.forward(feats, train=False, masks=masks)
+
+        def bwd(grads, needs):
+            demb, dlog = (None if g is None else g.contiguous().float() for g in grads)
+            if dlog is None:
+                dlog = torch.zeros(feats.shape[0], 2, device=be.device)
+            d = be.backward(demb, dlog, want_dfeats=bool(needs[0]))
+            return (d,)
+
+        return run_engine(self.param_set, lambda f: be.forward(f, train=True, masks=masks), bwd, feats)
 
     def backward(self, demb, dlogits):
         return self.backend.backward(demb, dlogits)
@@ -726,7 +768,8 @@ class AModel(torch.nn.Module):
         ``ssl_model.model.*`` tensor of the loaded fairseq checkpoint -- also the ones the features_only forward never reads --
         so the reference's strict ``load_state_dict`` (oc_classifier.py:340) accepts the file."""
         sd = self.backend.state_dict()
-        for k, v in self.ssl_model.full_state_dict().items():
+        full = self.ssl_model.full_state_dict().items() if hasattr(self.ssl_model, "full_state_dict") else ()
+        for k, v in full:
             sd["ssl_model.model." + k] = v.detach().clone() if torch.is_tensor(v) else v
         return sd
 
@@ -735,6 +778,6 @@ class AModel(torch.nn.Module):
         with the right shape -- a checkpoint can never leave random tensors in place silently."""
         self.backend.load_reference_params(sd, strict=strict)
         ssl = {k[len("ssl_model.model."):]: v for k, v in sd.items() if k.startswith("ssl_model.model.")}
-        if ssl or strict:
+        if (ssl or strict) and hasattr(self.ssl_model, "load_params"):
             self.ssl_model.load_params(ssl, strict=strict)
         return self

@@ -18,6 +18,7 @@ import torch
 
 from .. import ops
 from .._lib import ACT_GELU, ACT_GELU_GRAD, ACT_GELU_KEEP_GRAD, ACT_MUL_AUX, ACT_NONE, OCC_AF32_WBF16, OCC_BF16 as OCC_BF16_CODE, OCC_F32, OccError, dtype_code, require_gpu
+from ..autograd_bridge import attach_parameters, run_engine
 from ..ops import rowmap
 
 WS_CACHE = 12            # activation workspaces kept per model (one per distinct input shape)
@@ -75,11 +76,16 @@ def param_shapes(cfg):
     return s
 
 
-class XlsrFrontend:
+class XlsrFrontend(torch.nn.Module):
     """Frozen-weight forward engine.  ``params``: {fairseq name: tensor} (any device); ``dtype``:
-    torch.bfloat16 (MFMA bf16, f32 accumulate) or torch.float32 (exact-f32 MFMA parity path)."""
+    torch.bfloat16 (MFMA bf16, f32 accumulate) or torch.float32 (exact-f32 MFMA parity path).
+
+    An ``nn.Module`` only so that the fine-tuning subclasses can register their tensors as ``nn.Parameter``s under fairseq's names
+    (``ssl_model.model.encoder.layers.0.fc1.weight`` ...), as the reference's module tree has them (sslassist.py:25-29); the frozen
+    engine registers none (its operands are packed bf16 copies)."""
 
     def __init__(self, params, cfg, device="cuda", dtype=torch.bfloat16):
+        super().__init__()
         require_gpu()
         if dtype not in (torch.bfloat16, torch.float32):
             raise OccError("XlsrFrontend dtype must be bfloat16 or float32")
@@ -232,6 +238,8 @@ class SSLModel(torch.nn.Module):
     ``final_proj.*`` ...) are kept in ``extra_state`` and re-emitted by ``full_state_dict`` so a file saved here still loads in the
     reference's strict ``load_state_dict`` (oc_classifier.py:340)."""
 
+    _eval_at_init = True
+
     def __init__(self, device="cuda", cp_path=None, state_dict=None, cfg=None, dtype=torch.bfloat16, seed=0, finetune=False, synthetic=False,
                  train_cfg=None):
         super().__init__()
@@ -260,12 +268,34 @@ class SSLModel(torch.nn.Module):
             self.model = XlsrFullFineTuner(self._params, self.cfg, device=device)
         else:
             self.model = XlsrFrontend(self._params, self.cfg, device=device, dtype=dtype)
+        if self._eval_at_init:
+            self.model.eval()                  # xlsr.py:34 (sslassist.SSLModel has no such call: quirk 10 of SURVEY.md section 8a)
+        self.param_set = None
         if finetune:
             self.model.train_cfg = self.train_cfg
+            # every trainable tensor as an nn.Parameter named as in fairseq's module tree (a view of the flat master buffer), so that
+            # ``optim.Adam(aasist.parameters())`` (oc_training.py:324) holds XLS-R too
+            self.param_set = attach_parameters(self.model, self.model)
 
     def extract_feat(self, input_data):
-        with torch.no_grad():
-            return self.model.forward(input_data)
+        """sslassist.py:31-49 / xlsr.py:39-48.  Frozen engine: a plain forward.  Fine-tuning engine in training mode: fairseq's
+        train-mode forward (dropouts / layerdrop per ``train_cfg``), taped for ``loss.backward()`` through
+        ``autograd_bridge.EngineFunction``; in eval mode the deterministic forward."""
+        x = input_data[:, :, 0] if input_data.dim() == 3 else input_data
+        eng = self.model
+        if not self.finetune:
+            with torch.no_grad():
+                return eng.forward(x, out_dtype=torch.float32)
+        eng.sync_operands()
+        if not eng.training:                   # fairseq decides on the inner model's flag (``ssl.train()`` / ``aasist.train()`` set it)
+            with torch.no_grad():
+                return eng.forward(x, out_dtype=torch.float32)
+
+        def bwd(grads, needs):
+            eng.backward(grads[0].contiguous().float())
+            return (None,)
+
+        return run_engine(self.param_set, lambda w: eng.forward_train(w.to(eng.device, torch.float32).contiguous()), bwd, x)
 
     def forward(self, input_data):
         return self.extract_feat(input_data)
@@ -467,6 +497,33 @@ class XlsrFineTuner(XlsrFrontend):
             shp = self.tslots[name][1]
             if name.endswith(".w"):
                 tb.add(self.w[name], self.wT[name], shp[0], shp[1], ld_src=shp[1], ld_dst=shp[0])
+
+    def ref_views(self, flat):
+        """{fairseq name: VIEW of ``flat`` (self.P / self.G / same-sized buffer) in fairseq's shape}: q | k | v are row blocks of the
+        fused [3D, D] slot."""
+        v = lambda n: flat[self.tslots[n][0]: self.tslots[n][0] + self.tslots[n][2]].view(self.tslots[n][1])
+        out, D = {}, self.cfg.dim
+        for i in range(self.cfg.layers):
+            pre, a = "encoder.layers.%d" % i, "encoder.layers.%d.self_attn." % i
+            w, b = v("l%d.qkv.w" % i), v("l%d.qkv.b" % i)
+            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                out[a + n + ".weight"] = w[j * D:(j + 1) * D]; out[a + n + ".bias"] = b[j * D:(j + 1) * D]
+            out[a + "out_proj.weight"] = v("l%d.o.w" % i); out[a + "out_proj.bias"] = v("l%d.o.b" % i)
+            out[pre + ".self_attn_layer_norm.weight"] = v("l%d.ln1.g" % i); out[pre + ".self_attn_layer_norm.bias"] = v("l%d.ln1.b" % i)
+            out[pre + ".fc1.weight"] = v("l%d.fc1.w" % i); out[pre + ".fc1.bias"] = v("l%d.fc1.b" % i)
+            out[pre + ".fc2.weight"] = v("l%d.fc2.w" % i); out[pre + ".fc2.bias"] = v("l%d.fc2.b" % i)
+            out[pre + ".final_layer_norm.weight"] = v("l%d.ln2.g" % i); out[pre + ".final_layer_norm.bias"] = v("l%d.ln2.b" % i)
+        out["encoder.layer_norm.weight"] = v("enc_ln.g"); out["encoder.layer_norm.bias"] = v("enc_ln.b")
+        return out
+
+    def sync_operands(self):
+        """Re-derive the GEMM operands (bf16 mirror, W^T copies, weight-normed positional kernel) if anything wrote the f32 masters
+        through torch since the last refresh -- an ``optimizer.step()`` on the registered Parameters, a ``load_state_dict`` -- detected by
+        the version counter the Parameter views share with ``P``.  (OcTrainer's fused Adam kernel writes the mirror itself and calls
+        ``refresh_operands`` directly.)"""
+        if self.P._version != getattr(self, "_synced_version", -1):
+            self.refresh_operands(cast=True)
+            self._synced_version = self.P._version
 
     def export_params(self):
         """Trainable tensors back under their fairseq names (q/k/v split again)."""
@@ -997,6 +1054,19 @@ class XlsrFullFineTuner(XlsrFineTuner):
         out["post_extract_proj.weight"] = ("proj.w", None); out["post_extract_proj.bias"] = ("proj.b", None)
         out["encoder.pos_conv.0.weight_v"] = ("pos.v", None); out["encoder.pos_conv.0.weight_g"] = ("pos.g", lambda t: t.reshape(1, 1, -1))
         out["encoder.pos_conv.0.bias"] = ("pos.b", None)
+        return out
+
+    def ref_views(self, flat):
+        out = super().ref_views(flat)
+        v = lambda n: flat[self.tslots[n][0]: self.tslots[n][0] + self.tslots[n][2]].view(self.tslots[n][1])
+        for i in range(7):
+            pre = "feature_extractor.conv_layers.%d" % i
+            out[pre + ".0.weight"] = v("c0.w").view(512, 1, 10) if i == 0 else v("c%d.w" % i).permute(0, 2, 1)       # [n][tap][c] inside
+            out[pre + ".0.bias"] = v("c%d.b" % i); out[pre + ".2.1.weight"] = v("c%d.g" % i); out[pre + ".2.1.bias"] = v("c%d.be" % i)
+        out["layer_norm.weight"] = v("ln.g"); out["layer_norm.bias"] = v("ln.b")
+        out["post_extract_proj.weight"] = v("proj.w"); out["post_extract_proj.bias"] = v("proj.b")
+        out["encoder.pos_conv.0.weight_v"] = v("pos.v"); out["encoder.pos_conv.0.weight_g"] = v("pos.g").view(1, 1, -1)
+        out["encoder.pos_conv.0.bias"] = v("pos.b")
         return out
 
     def export_params(self):
