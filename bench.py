@@ -47,6 +47,7 @@ def parse_args(argv=None):
                     "delayed per-tensor scaling), as BASELINE configs[4] asks for XLS-R-1B; weight gradients stay bf16")
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the XLS-R gradients on the xGMI links (bf16 halves the 1.26 GB "
                     "payload; sums are widened back into the f32 gradient buffer before Adam).  Default f32 = the exact sum")
+    ap.add_argument("--rccl-channels", type=int, default=0, help="N > 1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS); 0 = RCCL's own choice (default)")
     ap.add_argument("--print-workload", action="store_true", help="print the workload tag of these flags (what scripts/pmc_summary.py stores in a PMC profile) and exit")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous only (gloo, no GPU call): every rank reports world size and its shard of the "
                     "utterance groups, rank 0 prints them as one JSON line")
@@ -62,15 +63,16 @@ def free_port():
     return port
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, args_ns=None):
     """--gpus N without a torchrun environment: start N ranks as children (one per GPU) BEFORE this process touches a GPU, pass their
     output through and exit with their status.  Replaces nn.DataParallel's single process (oc_training.py:328)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # RCCL's collectives run as kernels of one workgroup per channel.  The hot GEMMs launch one 128-KiB-LDS workgroup per CU (228 of
-    # 256 CUs for the N = 1024 launches): 16 channels keep the all-reduce inside the CUs those grids leave free, instead of turning a
-    # one-round GEMM launch into two.  16 channels x ~20 GB/s still move a layer's 50 MB slice in well under its backward time.
-    env.setdefault("NCCL_MAX_NCHANNELS", "16")
+    # RCCL's channel count is left alone: capping it (NCCL_MAX_NCHANNELS) would keep the collective inside the CUs the one-round GEMM
+    # launches leave free, but it can also cap xGMI all-reduce bandwidth for the 1.26 GB exchange, and neither effect has been measured on
+    # an 8-GPU node.  --rccl-channels N (or the caller's own NCCL_MAX_NCHANNELS) opts in; the value in force is printed in the bench line.
+    if getattr(args_ns, "rccl_channels", 0):
+        env["NCCL_MAX_NCHANNELS"] = str(args_ns.rccl_channels)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
     return subprocess.run(cmd, env=env).returncode
@@ -273,7 +275,7 @@ def pmc_traffic(tag):
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args))
     if args.dry_launch:
         sys.exit(dry_launch(args))
     if args.print_workload:

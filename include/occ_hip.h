@@ -192,7 +192,8 @@ int occ_fp8_update_scales(float* amax, float* scale, float* inv_scale, int64_t n
 int occ_gemm_variant(int v);
 /* Which kernel family the calling thread's last occ_gemm call launched (-1 before the first call): lets tests pin the dispatch. */
 enum { OCC_GEMM_KERNEL_OTHER = 0, OCC_GEMM_KERNEL_P8 = 8, OCC_GEMM_KERNEL_P8_FP8 = 9, OCC_GEMM_KERNEL_P8_TAIL = 10 /* eight-phase kernel + a small-tile launch for the last partial round */,
-       OCC_GEMM_KERNEL_P8_224 = 11 /* eight-phase kernel on 224-row tiles */ };
+       OCC_GEMM_KERNEL_P8_224 = 11 /* eight-phase kernel on 224-row tiles */,
+       OCC_GEMM_KERNEL_Q4 = 12 /* four-wave 256 x 128 kernel, two workgroups per CU (csrc/gemm_q4.hip) */ };
 int occ_gemm_last_kernel(void);
 
 

@@ -664,6 +664,22 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     // tiles) keeps the small-tile kernels.  OCC_GEMM_P8=0 switches it off; variant 30 forces it.
     static const int p8_env = getenv("OCC_GEMM_P8") ? atoi(getenv("OCC_GEMM_P8")) : 1;
     const bool p8_ok = d->ab_dtype == OCC_BF16 && d->K % 64 == 0 && nseg == 1 && ng == 1 && d->N >= 256 && d->M >= 256 && p8_fits;
+    // The four-wave 256 x 128 kernel, two workgroups per CU (gemm_q4.hip).  Variant 40 / 41 force it (256- / 224-row tiles); by default
+    // (q4_env) it takes the launches of the eight-phase kernel whose epilogue is long against the K loop -- see q4_pays below.
+    static const int q4_env = getenv("OCC_GEMM_Q4") ? atoi(getenv("OCC_GEMM_Q4")) : 0;
+    // q4_env bits: 1 = N >= 3072 with K <= 1536 (qkv / fc1 forward, fc2's input gradient: the two-tensor and GELU epilogues);
+    // 2 = N < 3072, K <= 1536, f32 result (out-proj forward: f32 store + f32 residual read); 4 = every launch the eight-phase kernel would take
+    const bool q4_pays = variant == 1 && q4_env && rows_epilogue_applies(a) && d->M >= 2048 &&
+                         (((q4_env & 1) && d->N >= 3072 && d->K <= 1536) || ((q4_env & 2) && d->N < 3072 && d->K <= 1536 && d->c_dtype == OCC_F32) || (q4_env & 4));
+    if (p8_ok && (variant == 40 || variant == 41 || q4_pays)) {
+        OCC_CHECK_ARG(variant == 40 || rows_epilogue_applies(a), "occ_gemm: the 224-row tile has no epilogue for this combination");
+        g_last_kernel = OCC_GEMM_KERNEL_Q4;
+        static const int q4_rows = getenv("OCC_Q4_ROWS") ? atoi(getenv("OCC_Q4_ROWS")) : 256;
+        gemm_q4_launch(a, s, variant == 41 ? 224 : (variant == 40 ? 256 : q4_rows));
+        if (d->c_colsum) colsum_finalize(a, d->c_colsum, s);
+        OCC_LAUNCH_CHECK("occ_gemm");
+        return OCC_OK;
+    }
     if (p8_ok && (variant == 30 || variant == 31 || (variant == 1 && p8_env && nbm256 * occ_cdiv(d->N, 256) * 10 >= 7ll * cu_count()))) {
         // One workgroup per CU: a launch takes ceil(tiles / CUs) tile times, so 800 tiles of 256 rows on 256 CUs (fc1 at bs 64) pay four
         // rounds for 3.125 rounds of work and 200 tiles (N = 1024) leave 56 CUs idle.  Three forms, costed in tile-row units:

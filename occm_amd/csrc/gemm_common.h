@@ -32,6 +32,7 @@ struct GemmArgs {
     int ksplit;              // > 1: the K range is cut into ksplit pieces handled by different workgroups, C += alpha*acc with f32 atomics
     int slabs_per_split;
     int tile_rows;           // default 128x128 kernels: rows per output tile (multiple of 16, <= 128; the LDS image stays 128 rows) -- see occ_gemm
+    int q4_mode, q4_first, q4_delay;   // gemm_q4.hip: start stagger of the presumably second workgroup of a CU (speed only)
 #ifdef P8_DIAG
     unsigned long long* diag;   // scripts/diag_p8.hip only: per workgroup {clock at entry, after the prologue, after the K loop, at exit, realtime entry, realtime exit}
 #endif
@@ -515,5 +516,7 @@ inline int cu_count() {
 
 // 256x256 eight-phase kernel (gemm_p8.hip); the caller has checked: bf16 operands, K % 64 == 0, one K segment, one group
 void gemm_p8_launch(GemmArgs& a, hipStream_t s, int fmt = 0, int tile_rows = 256);      // tile_rows 224: only with rows_epilogue_applies(a)
+// 256x128 four-wave kernel, two workgroups per CU (gemm_q4.hip); same preconditions, bf16 only
+void gemm_q4_launch(GemmArgs& a, hipStream_t s, int tile_rows = 256);
 
 }  // namespace occ_gemm_detail

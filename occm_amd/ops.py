@@ -62,7 +62,7 @@ def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, 
     if c_f8 is not None:                       # (u8 buffer, scale scalar, amax scalar, fp8 format): fp8 copy of the bf16 result from the same epilogue
         d.c_f8, d.c_f8_scale, d.c_f8_amax, d.c_f8_fmt = c_f8[0].data_ptr(), c_f8[1].data_ptr(), c_f8[2].data_ptr(), int(c_f8[3])
     if c_colsum is not None:                   # f32 [N] += column sums of the bf16 result (bias gradient), from the same epilogue
-        ws = small_scratch()
+        ws = small_scratch(2 * ((int(M) + 223) // 224) * int(N))          # one partial row per 112-row half tile (occ_gemm checks the size)
         d.c_colsum, d.c_colsum_ws, d.c_colsum_ws_floats = c_colsum.data_ptr(), ws.data_ptr(), ws.numel()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -269,15 +269,18 @@ def dropout_ex(x, y, mask, p, seed=0, stream_id=0, generate=False, residual=None
     return y
 
 
-_SCRATCH = {}
+_SCRATCH, _SCRATCH_RETIRED = {}, []
 
 
 def small_scratch(nfloats=512 * 2048):
-    """Per (device, stream) f32 scratch for kernels that hand partial sums to a second launch (calls sharing it are ordered on that stream)."""
+    """Per (device, stream) f32 scratch of AT LEAST ``nfloats`` for kernels that hand partial sums to a second launch (calls sharing it are
+    ordered on that stream).  It only grows; a replaced buffer stays allocated because a captured HIP graph may still hold its address."""
     key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     t = _SCRATCH.get(key)
     if t is None or t.numel() < nfloats:
-        t = _SCRATCH[key] = torch.empty(nfloats, device="cuda", dtype=torch.float32)
+        if t is not None:
+            _SCRATCH_RETIRED.append(t)
+        t = _SCRATCH[key] = torch.empty(max(int(nfloats), 512 * 2048), device="cuda", dtype=torch.float32)
     return t
 
 
@@ -285,7 +288,7 @@ def layernorm_bwd_ex(dy, x, gamma, beta, dres, dx, dx_bf16, dx_bf16_map, dgamma,
     """General LayerNorm backward (x f32 or bf16, optional fused GELU', f32 and/or row-mapped bf16 outputs)."""
     C = x.shape[-1]
     rows = x.numel() // C
-    sc = small_scratch()
+    sc = small_scratch(256 * 2 * C)          # at most 256 workgroups leave partial sums (frontend_bwd.hip lnb_blocks)
     check(lib().occ_layernorm_bwd_ex(_p(dy), dtype_code(dy), _p(x), dtype_code(x), _p(gamma), _p(beta), _p(dres), _p(dx), _p(dx_bf16),
                                      ctypes.byref(dx_bf16_map) if dx_bf16_map is not None else None, _p(dgamma), _p(dbeta), rows, C, float(eps),
                                      int(gelu), ptr(sc), sc.numel(), stream_ptr()), "occ_layernorm_bwd_ex")
@@ -294,7 +297,7 @@ def layernorm_bwd_ex(dy, x, gamma, beta, dres, dx, dx_bf16, dx_bf16_map, dgamma,
 def layernorm_bwd(dy, x, gamma, dres, dx, dgamma, dbeta, eps=1e-5, dx_bf16=None):
     C = x.shape[-1]
     rows = x.numel() // C
-    sc = small_scratch()
+    sc = small_scratch(256 * 2 * C)          # at most 256 workgroups leave partial sums (frontend_bwd.hip lnb_blocks)
     check(lib().occ_layernorm_bwd(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(dgamma), ptr(dbeta), rows, C,
                                   float(eps), ptr(sc), sc.numel(), stream_ptr()), "occ_layernorm_bwd")
     return dx
@@ -312,7 +315,7 @@ def layernorm_bwd_fused(dy, x, gamma, dres, dx, dgamma, dbeta, dx_bf16, dbias=No
     """layernorm_bwd with the bias gradient of the preceding Linear (column sums of dx) and / or the e5m2 copy of the bf16 dx folded in."""
     C = x.shape[-1]
     rows = x.numel() // C
-    sc = small_scratch()
+    sc = small_scratch(256 * 3 * C)
     check(lib().occ_layernorm_bwd_fused(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(dgamma), ptr(dbeta), ptr(dbias),
                                         ptr(dx_f8), ptr(f8_scale), ptr(f8_amax), rows, C, float(eps), ptr(sc), sc.numel(), stream_ptr()), "occ_layernorm_bwd_fused")
     return dx
@@ -407,7 +410,9 @@ def ce_loss(logits, labels, scale=1.0, want_grad=False):
 
 
 def pair_dist_loss(emb, pairs, weights, bias=0.0, relu=False, scale=1.0, want_grad=False):
-    """loss [1] = act(bias + sum_k weights[k] * ||emb[i_k] - emb[j_k] + 1e-6||); pairs = [(i, j), ...] (custom_loss.py:32-74)."""
+    """loss [1] = act(bias + sum_k weights[k] * ||emb[i_k] - emb[j_k] + 1e-6||); pairs = [(i, j), ...] (custom_loss.py:32-74).
+    As in every loss kernel of the library the returned VALUE is the unweighted loss and ``scale`` (the loss weight of the training step)
+    multiplies the GRADIENT only: demb = d(scale * loss) / d emb."""
     _dev(emb)
     R, E = emb.shape
     if any(not (0 <= i < R and 0 <= j < R) for i, j in pairs):

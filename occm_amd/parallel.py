@@ -47,15 +47,13 @@ class FlatGradAllReducer:
     def __init__(self, flat_grad, bucket_bytes=64 << 20, group=None, wire_dtype=None):
         """wire_dtype=torch.bfloat16: the gradients cross the links as bf16 (half the payload: 0.63 GB instead of 1.26 GB for XLS-R-300M)
         -- each slice is rounded into a bf16 staging buffer, summed by the collective in bf16 and widened back into the f32 buffer the
-        optimizer reads (f32 master accumulation after the reduce).  Default (None, or OCC_GRAD_WIRE unset): f32 on the wire, the
-        bit-exact sum of the ranks' gradients."""
+        optimizer reads (f32 master accumulation after the reduce).  Default (None): f32 on the wire, the bit-exact sum of the ranks' gradients.
+        (``OCC_GRAD_WIRE=bf16`` is read by ``OcTrainer`` and applied to the XLS-R reducer only: the small back-end buffer stays f32.)"""
         self.flat = flat_grad
         self.group = group
         self.bucket = max(1, bucket_bytes // flat_grad.element_size())
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._started, self._works = [], []
-        if wire_dtype is None and os.environ.get("OCC_GRAD_WIRE", "").lower() in ("bf16", "bfloat16"):
-            wire_dtype = torch.bfloat16
         if wire_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError("wire_dtype must be None / float32 / bfloat16")
         self.wire = wire_dtype if (wire_dtype == torch.bfloat16 and flat_grad.dtype == torch.float32) else None
@@ -91,7 +89,8 @@ class FlatGradAllReducer:
         if self.world == 1 or hi <= lo:
             return []
         self._started.append((int(lo), int(hi)))
-        return self._launch(int(lo), int(hi))
+        works = self._launch(int(lo), int(hi))
+        return works if self.wire is None else []            # bf16 wire: the handles cover the STAGING buffer, not the f32 slice a caller would read
 
     def all_reduce(self, async_op=False):
         if self.world == 1:

@@ -66,7 +66,10 @@ class OcTrainer:
         # ran beside by as much as they hid (51.70 vs 51.68 / 52.38 ms per step, GEMM family 32.0 -> 33.4 ms); OCC_OPT_OVERLAP=1 enables it.
         self.overlap_optimizer = os.environ.get("OCC_OPT_OVERLAP", "0") == "1"
         self._opt_stream = None
-        # grad_wire_dtype=torch.bfloat16: the XLS-R gradients (1.26 GB f32) cross xGMI as bf16; the small back-end buffer stays f32
+        # grad_wire_dtype=torch.bfloat16 (or OCC_GRAD_WIRE=bf16): the XLS-R gradients (1.26 GB f32) cross xGMI as bf16; the small back-end
+        # buffer stays f32
+        if grad_wire_dtype is None and os.environ.get("OCC_GRAD_WIRE", "").lower() in ("bf16", "bfloat16"):
+            grad_wire_dtype = torch.bfloat16
         self.reducers = [FlatGradAllReducer(g, wire_dtype=grad_wire_dtype if i == 1 else None) for i, g in enumerate(flat)]
         self.reducer = self.reducers[0]
         self.last = None

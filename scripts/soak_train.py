@@ -39,7 +39,7 @@ for i in range(steps):
     cur, nxt = nxt, batch()
     lc, ld = tr.step(cur, labels, next_wav=nxt)
     losses.append((lc, ld))
-    if i == 20:
+    if i == min(20, steps - 1):
         torch.cuda.synchronize(); mem0 = torch.cuda.max_memory_allocated()
     if i % 40 == 39:
         print("step %d  loss_d %.4f" % (i + 1, float(ld)), flush=True)

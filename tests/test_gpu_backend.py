@@ -353,19 +353,27 @@ def test_trainer_prefetch_pipeline_equals_sequential_steps():
             seen.append(feats.clone())
             return fwd(feats, **kw)
         tr.be.forward = spy
-        out = []
+        out, p1 = [], None
         for i, w in enumerate(wavs):
             nxt = wavs[i + 1] if pipelined and i + 1 < len(wavs) else None
             lc, ld = tr.step(w, labels, next_wav=nxt)
             out.append((float(lc), float(ld)))
-        return out, seen
+            if i == 0:
+                p1 = tr.be.P.clone()
+        return out, seen, p1
 
-    seq, f_seq = run(False)
-    pip, f_pip = run(True)
+    seq, f_seq, p_seq = run(False)
+    pip, f_pip, p_pip = run(True)
     assert len(f_seq) == len(f_pip) == len(wavs)
     for a, b in zip(f_seq, f_pip):
         assert torch.equal(a, b)
     assert seq[0] == pip[0]
+    # the sharp statement after one update: both orders applied Adam to gradients that differ only by float-atomic noise, so the parameters
+    # agree except where a noise-level gradient flips the sign of Adam's first (sign-like, +-lr) update -- a pipeline that trained on a
+    # wrong or stale tensor would move most elements by up to 2 lr
+    dp = (p_seq - p_pip).abs()
+    frac = float((dp > 0.1 * 1e-4).float().mean())
+    assert float(dp.max()) <= 2.1e-4 and frac < 0.02, (float(dp.max()), frac)
     (a, b), (c, d) = seq[1], pip[1]             # after one update; further steps of this tiny model amplify the atomics' noise
     # (run-to-run spread of the second step's losses, measured over this round's runs: 0.2-2.1 % -- a one-ulp difference flips a top-k
     # graph-pooling choice in the random-initialised back-end; a wrong feature tensor would already have failed the bit-equality above)
