@@ -93,3 +93,32 @@ def test_load_audio_reads_flac_like_wav(tmp_path):
     p2.write_bytes(fw.encode(st, blocksize=1024, stereo="left_side"))
     m, _ = du.load_audio(str(p2))
     np.testing.assert_allclose(m, st.mean(1) / 32768.0, atol=1e-7)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_rfc9639_appendix_example_streams_known_answers(k):
+    """The three example files of RFC 9639, Appendix D (written by reference libFLAC 1.3.3, as the vendor string inside example 2 says):
+    tests/golden/flac_rfc9639_example{1,2,3}.flac are the RFC's byte listings -- 1: one stereo 16-bit verbatim frame with wasted bits;
+    2: seek table + Vorbis comment + padding blocks, two frames, fixed predictors with partitioned Rice coding, side-channel stereo; 3: 8-bit
+    mono LPC.  These are streams this repository's encoder (tests/flac_writer.py) did not write.  Known answers, none of them the decoder's
+    own arithmetic: the MD5 signature in each STREAMINFO (computed by libFLAC over the PCM it encoded) re-computed here with hashlib, the
+    sample counts of the STREAMINFO blocks and the decoded values the RFC tabulates (example 3's 24 samples; the first samples of 1 and 2)."""
+    import hashlib
+    from conftest import GOLDEN, golden
+    raw = open(os.path.join(GOLDEN, "flac_rfc9639_example%d.flac" % k), "rb").read()
+    out, fs, bps = du.decode_flac_bytes(raw)
+    E = golden("flac_rfc9639_expected.npz")
+    np.testing.assert_array_equal(out, E["pcm%d" % k])
+    assert (fs, bps) == (int(E["fs%d" % k]), int(E["bps%d" % k]))
+    # STREAMINFO: 4 bytes "fLaC", 4 bytes block header, then 18 bytes of fields followed by the 16-byte MD5 of the interleaved little-endian PCM
+    si = raw[8:8 + 34]
+    total = ((si[13] & 0x0f) << 32) | int.from_bytes(si[14:18], "big")
+    assert total == out.shape[0] == {1: 1, 2: 19, 3: 24}[k]
+    pcm = out.astype({8: "<i1", 16: "<i2"}[bps]).tobytes()
+    assert hashlib.md5(pcm).digest() == si[18:34]
+    if k == 1:
+        assert out.tolist() == [[25588, 10416]]
+    if k == 2:
+        assert out[0].tolist() == [10372, 6070] and out[16].tolist() == [-15486, -9072]          # first sample of either frame (16 + 3 samples)
+    if k == 3:
+        assert out[:, 0].tolist() == [0, 79, 111, 78, 8, -61, -90, -68, -13, 42, 67, 53, 13, -27, -46, -38, -12, 14, 24, 19, 6, -4, -5, 0]
