@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 L_SAMPLES = 64000
 BS_FINETUNE, BS_FROZEN = 64, 32
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-GEMM_SOURCES = ("gemm.hip", "gemm_common.h", "gemm_tn.hip", "gemm_p8.hip", "gemm_tn_p8.hip")
+GEMM_SOURCES = ("gemm.hip", "gemm_common.h", "gemm_tn.hip", "gemm_p8.hip", "gemm_q4.hip", "gemm_tn_p8.hip")
 
 
 def parse_args(argv=None):
@@ -47,6 +47,10 @@ def parse_args(argv=None):
                     "delayed per-tensor scaling), as BASELINE configs[4] asks for XLS-R-1B; weight gradients stay bf16")
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the XLS-R gradients on the xGMI links (bf16 halves the 1.26 GB "
                     "payload; sums are widened back into the f32 gradient buffer before Adam).  Default f32 = the exact sum")
+    ap.add_argument("--ssl-dropouts", default=None, metavar="P_RES,P_ATT,P_ACT,P_LAYERDROP",
+                    help="not the headline: fairseq's train-mode probabilities of the fine-tuned front-end (dropout, attention_dropout, activation_dropout, "
+                         "encoder_layerdrop), e.g. 0.1,0.1,0.1,0.05 -- the published XLS-R pre-training configuration the headline uses has all of them 0; a "
+                         "fine-tuning checkpoint's cfg may not (the reference keeps XLS-R in train mode, oc_training.py:352)")
     ap.add_argument("--rccl-channels", type=int, default=0, help="N > 1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS); 0 = RCCL's own choice (default)")
     ap.add_argument("--print-workload", action="store_true", help="print the workload tag of these flags (what scripts/pmc_summary.py stores in a PMC profile) and exit")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous only (gloo, no GPU call): every rank reports world size and its shard of the "
@@ -247,7 +251,8 @@ def gemm_source_sha():
 
 def workload_tag(args, finetune, bs, rawboost):
     """Identifies the measured workload (model, back-end, batch, dtype, augmentation): a PMC profile is quoted only for its own workload."""
-    return "xlsr-%s/%s/%s/bs%d/rawboost%d/%s" % (args.xlsr, args.backend, ("finetune-" + str(finetune)) if finetune else "frozen", bs, rawboost, "fp8" if args.fp8 else "bf16")
+    return "xlsr-%s/%s/%s/bs%d/rawboost%d/%s" % (args.xlsr, args.backend, ("finetune-" + str(finetune)) if finetune else "frozen", bs, rawboost, "fp8" if args.fp8 else "bf16") + \
+        (("/drop" + args.ssl_dropouts) if getattr(args, "ssl_dropouts", None) else "")
 
 
 def pmc_traffic(tag):
@@ -312,6 +317,11 @@ def main():
         if not finetune:
             raise SystemExit("bench.py: --fp8 applies to the fine-tuned front-end")
         model.ssl_model.model.enable_fp8()
+    if args.ssl_dropouts:
+        if not finetune:
+            raise SystemExit("bench.py: --ssl-dropouts applies to the fine-tuned front-end (the frozen one runs its deterministic forward)")
+        pr, pa, pc, pl = [float(v) for v in args.ssl_dropouts.split(",")]
+        model.ssl_model.model.train_cfg = xlsr.XlsrTrainCfg(dropout=pr, attention_dropout=pa, activation_dropout=pc, encoder_layerdrop=pl)
     model.train()
     trainer = OcTrainer(model, lr=1e-5, w_compact=wc, w_descr=wd, train_frontend=bool(finetune), rawboost_algo=rawboost,
                         group_size=12 if bs % 12 == 0 else None, rank=rank, grad_wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
@@ -396,7 +406,7 @@ def main():
         cpu = cpu_baseline(bool(finetune), rawboost)
     if rank == 0:
         cfgno = "configs[1]" if not finetune else ("configs[2]" if world == 1 else "configs[3]")
-        std = not args.fp8 and args.backend == "aasist" and args.xlsr == "300m" and finetune in (False, "full") and bs == (BS_FINETUNE if finetune else BS_FROZEN) and \
+        std = not args.fp8 and not args.ssl_dropouts and args.backend == "aasist" and args.xlsr == "300m" and finetune in (False, "full") and bs == (BS_FINETUNE if finetune else BS_FROZEN) and \
             rawboost == (5 if finetune else 0)
         wl = "XLSR-%s %s + %s backend, bs=%d per GPU, 64000-sample utterances%s (%s)" % (
             args.xlsr.upper(), ("fine-tuned end to end" if finetune == "full" else "fine-tuned (encoder only)") if finetune else "frozen frontend",
@@ -409,6 +419,8 @@ def main():
                           "frontend": ("bf16 MFMA fwd + bwd, f32 accumulate, f32 master weights and gradients, Adam over all 315.4 M parameters" if finetune == "full" else
                                        "bf16 MFMA, f32 accumulate" + (", HIP-graph replay" if graph is not None else "") +
                                        (", features of step i+1 computed on a side stream during step i's back-end" if overlap else "")),
+                          "frontend_train_mode": (repr(fe.train_cfg) + " (fairseq train-mode probabilities in force; the published XLS-R configuration has them all 0)"
+                                                  if finetune else "frozen: deterministic forward, no dropout"),
                           "backend": ("fwd+bwd, f32 storage, bf16-MFMA GEMMs and weight gradients (f32 accumulate), dropout on, Adam lr=1e-5" if args.backend == "aasist"
                                       else "SE-ResNet34 fwd+bwd, f32 storage, bf16-MFMA convolutions and weight gradients (f32 accumulate), Adam lr=1e-5"),
                           "gradient_exchange": "none (1 rank)" if world == 1 else "RCCL all-reduce of the flat gradients (%s on the wire, f32 accumulation), per transformer layer, overlapped with backward; NCCL_MAX_NCHANNELS=%s" % (args.grad_wire, os.environ.get("NCCL_MAX_NCHANNELS", "default")),

@@ -385,10 +385,17 @@ int occ_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const
  * sslassist.py:48; evaluation scores un-padded batch-1 utterances of any length, oc_classifier.py:185-193).
  * qkv: [B*T, 3*D] rows (q | k | v); scores are scale * q.k (fairseq scales q by hd^-0.5); out: [B*T, D].
  * bf16, head_dim 64: MFMA kernels, any T (T <= 256: whole key set on chip; longer: keys streamed in blocks of 128 with the
- * online-softmax recurrence).  f32 (parity path) or other head dims: LDS kernel, T limited by 160 KiB of LDS (~300 at hd 64).
+ * online-softmax recurrence).  f32 (parity path) or other head dims: f32-arithmetic LDS kernels, any T (the whole head on chip while
+ * it fits 160 KiB of LDS, ~300 frames at hd 64; keys streamed in blocks of 64 with the online-softmax recurrence beyond).
  * lse (optional, f32 [B*H, T], MFMA kernels only): log2-sum-exp2 of the scaled scores, kept for backward.                */
 int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd,
                   int64_t ld_qkv, int64_t ld_out, float scale, float* lse, void* stream);
+/* The same on a zero-padded batch of utterances of unequal length (scoring in length-sorted batches instead of the reference's
+ * one-utterance loop, oc_classifier.py:182-186, 256-261): kv_len int32 [B] (device) = valid frames of each utterance; keys at or past
+ * it are masked, so rows [0, kv_len[b]) equal the un-padded single-utterance result; rows past it are not meaningful.
+ * f32-arithmetic kernels (storage f32 or bf16), any T.                                                                    */
+int occ_attention_varlen(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd,
+                         int64_t ld_qkv, int64_t ld_out, float scale, const int32_t* kv_len, void* stream);
 /* ---- backward of the transformer encoder (fine-tuning; autograd of fairseq's pre-LN TransformerSentenceEncoderLayer) ---- */
 /* dst[c, r] = bf16(src[r, c]) (src f32 or bf16 [rows, ld_src], dst bf16 [cols, ld_dst >= rows]): K-contiguous operands for the
  * weight-gradient GEMMs dW = dY^T X, which then run on the same bf16 MFMA GEMM as the forward.                */

@@ -228,10 +228,12 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
 // lanes = head dims for the weighted sum.  Short sequences only (T*(hd+1)*8 + ... <= 160 KiB).
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H, int hd,
-                                                       long long ld_qkv, long long ld_out, float scale, int qsplit) {
+                                                       long long ld_qkv, long long ld_out, float scale, int qsplit, const int* __restrict__ kv_len) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = H * hd;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    // kv_len: keys (= valid frames) of utterance b in a zero-padded batch; rows past it are neither attended to nor meaningful as queries
+    const int Tk = kv_len ? min(max(kv_len[b], 1), Tn) : Tn;
     const int hp = hd + 1;
     float* Ks = sm;                       // [Tn][hd+1]
     float* Vs = Ks + (size_t)Tn * hp;     // [Tn][hd+1]
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     float* qw = Qs + wave * hd;
     const int rows_per = (Tn + qsplit - 1) / qsplit;
     const int q_begin = blockIdx.y * rows_per, q_end = min(Tn, q_begin + rows_per);
-    const int nkey = (Tn + 63) / 64;
+    const int nkey = (Tk + 63) / 64;
     for (int qi = q_begin + wave; qi < q_end; qi += 4) {
         for (int d = lane; d < hd; d += 64) qw[d] = occ_load_f32(base + (size_t)qi * ld_qkv + d) * scale;
         __builtin_amdgcn_wave_barrier();
@@ -258,29 +260,104 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         for (int kb = 0; kb < nkey; ++kb) {
             const int key = kb * 64 + lane;
             float s = -3.0e38f;
-            if (key < Tn) {
+            if (key < Tk) {
                 s = 0.f;
                 const float* kr = Ks + key * hp;
                 for (int d = 0; d < hd; ++d) s = fmaf(qw[d], kr[d], s);
             }
             mx = fmaxf(mx, s);
-            if (key < Tn) pw[key] = s;
+            if (key < Tk) pw[key] = s;
         }
         mx = wave_max(mx);
         float sum = 0.f;
         for (int kb = 0; kb < nkey; ++kb) {
             const int key = kb * 64 + lane;
-            if (key < Tn) { const float p = expf(pw[key] - mx); pw[key] = p; sum += p; }
+            if (key < Tk) { const float p = expf(pw[key] - mx); pw[key] = p; sum += p; }
         }
         sum = wave_sum(sum);
         __builtin_amdgcn_wave_barrier();
         const float inv = 1.0f / sum;
         for (int d = lane; d < hd; d += 64) {
             float o = 0.f;
-            for (int key = 0; key < Tn; ++key) o = fmaf(pw[key], Vs[key * hp + d], o);
+            for (int key = 0; key < Tk; ++key) o = fmaf(pw[key], Vs[key * hp + d], o);
             occ_store_f32(out + ((size_t)b * Tn + qi) * ld_out + (size_t)h * hd + d, o * inv);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
+// Any-length form of the kernel above (the f32 scoring path on utterances longer than ~6 s, whose K and V of a head no longer fit in
+// LDS): one workgroup per (batch, head, 32 queries), keys streamed through LDS in blocks of 64 with the online-softmax recurrence; a wave
+// owns 8 queries, lanes = keys for the scores and = head dims for the weighted sum.  f32 arithmetic throughout (expf, not exp2).
+template <typename T>
+__global__ __launch_bounds__(256) void attention_stream_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H, int hd,
+                                                              long long ld_qkv, long long ld_out, float scale, const int* __restrict__ kv_len) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int KB = 64, QB = 32, QW = QB / 4;
+    const int D = H * hd, hp = hd + 1;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int Tk = kv_len ? min(max(kv_len[b], 1), Tn) : Tn;
+    float* Ks = sm;                       // [KB][hd+1]
+    float* Vs = Ks + KB * hp;             // [KB][hd+1]
+    float* Qs = Vs + KB * hp;             // [QB][hd], pre-scaled
+    float* Ps = Qs + QB * hd;             // [4 waves][KB]
+    const T* base = qkv + (size_t)b * Tn * ld_qkv + (size_t)h * hd;
+    const int q0 = blockIdx.y * QB;
+    for (int i = threadIdx.x; i < QB * hd; i += 256) {
+        const int q = i / hd, d = i - q * hd;
+        Qs[i] = q0 + q < Tn ? occ_load_f32(base + (size_t)(q0 + q) * ld_qkv + d) * scale : 0.f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* pw = Ps + wave * KB;
+    float m[QW], l[QW], o[QW][2];
+#pragma unroll
+    for (int j = 0; j < QW; ++j) { m[j] = -3.0e38f; l[j] = 0.f; o[j][0] = 0.f; o[j][1] = 0.f; }
+    for (int k0 = 0; k0 < Tk; k0 += KB) {
+        __syncthreads();                  // the previous block's readers are done (and Qs is written before the first use)
+        for (int i = threadIdx.x; i < KB * hd; i += 256) {
+            const int t = i / hd, d = i - t * hd;
+            const bool ok = k0 + t < Tk;
+            Ks[t * hp + d] = ok ? occ_load_f32(base + (size_t)(k0 + t) * ld_qkv + D + d) : 0.f;
+            Vs[t * hp + d] = ok ? occ_load_f32(base + (size_t)(k0 + t) * ld_qkv + 2 * D + d) : 0.f;
+        }
+        __syncthreads();
+        const bool valid = k0 + lane < Tk;
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+            const float* qw = Qs + (wave * QW + j) * hd;
+            const float* kr = Ks + lane * hp;
+            float sc = 0.f;
+            for (int d = 0; d < hd; ++d) sc = fmaf(qw[d], kr[d], sc);
+            const float mn = fmaxf(m[j], wave_max(valid ? sc : -3.0e38f));
+            const float alpha = expf(m[j] - mn);
+            const float p = valid ? expf(sc - mn) : 0.f;
+            l[j] = l[j] * alpha + wave_sum(p);
+            m[j] = mn;
+            pw[lane] = p;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int d = lane + e * 64;
+                if (d < hd) {
+                    float a = o[j][e] * alpha;
+                    for (int key = 0; key < KB; ++key) a = fmaf(pw[key], Vs[key * hp + d], a);
+                    o[j][e] = a;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+        const int qi = q0 + wave * QW + j;
+        if (qi >= Tn) continue;
+        const float inv = 1.0f / l[j];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int d = lane + e * 64;
+            if (d < hd) occ_store_f32(out + ((size_t)b * Tn + qi) * ld_out + (size_t)h * hd + d, o[j][e] * inv);
+        }
     }
 }
 
@@ -717,6 +794,43 @@ void launch_attention_mfma(const void* qkv, void* out, int B, int T, int H, long
 
 }  // namespace
 
+// f32-arithmetic attention (storage f32 or bf16): the whole-head kernel while K and V of a head fit in LDS, the streaming kernel beyond
+// (any T).  kv_len (optional, device int32 [B]): valid frames per utterance of a zero-padded batch.
+static int attention_f32_arith(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd, int64_t ld_qkv, int64_t ld_out,
+                               float scale, const int32_t* kv_len, hipStream_t s) {
+    if (dtype != OCC_F32 && dtype != OCC_BF16) { occ_set_error("occ_attention: dtype must be f32 or bf16"); return OCC_EUNSUPPORTED; }
+    const size_t shm = ((size_t)2 * T * (hd + 1) + 4 * T + 4 * hd) * sizeof(float);
+    hipError_t e;
+    if (shm <= 160 * 1024) {
+        const int qsplit = 4;
+        const dim3 grid((unsigned)(B * H), qsplit), block(256);
+        if (dtype == OCC_F32) {
+            e = hipFuncSetAttribute((const void*)attention_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            if (e != hipSuccess) { occ_set_error("occ_attention: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+            hipLaunchKernelGGL(attention_kernel<float>, grid, block, shm, s, (const float*)qkv, (float*)out, (int)T, (int)H, (int)hd, (long long)ld_qkv, (long long)ld_out, scale, qsplit, kv_len);
+        } else {
+            e = hipFuncSetAttribute((const void*)attention_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            if (e != hipSuccess) { occ_set_error("occ_attention: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+            hipLaunchKernelGGL(attention_kernel<unsigned short>, grid, block, shm, s, (const unsigned short*)qkv, (unsigned short*)out, (int)T, (int)H, (int)hd, (long long)ld_qkv, (long long)ld_out, scale, qsplit, kv_len);
+        }
+        OCC_LAUNCH_CHECK("occ_attention");
+        return OCC_OK;
+    }
+    const size_t shm2 = ((size_t)2 * 64 * (hd + 1) + 32 * hd + 4 * 64) * sizeof(float);
+    const dim3 grid((unsigned)(B * H), (unsigned)((T + 31) / 32)), block(256);
+    if (dtype == OCC_F32) {
+        e = hipFuncSetAttribute((const void*)attention_stream_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+        if (e != hipSuccess) { occ_set_error("occ_attention: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+        hipLaunchKernelGGL(attention_stream_kernel<float>, grid, block, shm2, s, (const float*)qkv, (float*)out, (int)T, (int)H, (int)hd, (long long)ld_qkv, (long long)ld_out, scale, kv_len);
+    } else {
+        e = hipFuncSetAttribute((const void*)attention_stream_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+        if (e != hipSuccess) { occ_set_error("occ_attention: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
+        hipLaunchKernelGGL(attention_stream_kernel<unsigned short>, grid, block, shm2, s, (const unsigned short*)qkv, (unsigned short*)out, (int)T, (int)H, (int)hd, (long long)ld_qkv, (long long)ld_out, scale, kv_len);
+    }
+    OCC_LAUNCH_CHECK("occ_attention(stream)");
+    return OCC_OK;
+}
+
 extern "C" {
 
 int occ_layernorm(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int64_t rows, int64_t C,
@@ -825,22 +939,15 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
         return OCC_OK;
     }
     OCC_CHECK_ARG(!lse, "occ_attention: the log-sum-exp output needs the bf16 / head_dim 64 MFMA path");
-    const size_t shm = ((size_t)2 * T * (hd + 1) + 4 * T + 4 * hd) * sizeof(float);
-    OCC_CHECK_ARG(shm <= 160 * 1024, "occ_attention: T=%ld hd=%ld needs %zu B of LDS (> 160 KiB)", (long)T, (long)hd, shm);
-    const int qsplit = 4;
-    const dim3 grid((unsigned)(B * H), qsplit), block(256);
-    hipError_t e;
-    if (dtype == OCC_F32) {
-        e = hipFuncSetAttribute((const void*)attention_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) { occ_set_error("occ_attention: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
-        hipLaunchKernelGGL(attention_kernel<float>, grid, block, shm, s, (const float*)qkv, (float*)out, (int)T, (int)H, (int)hd, (long long)ld_qkv, (long long)ld_out, scale, qsplit);
-    } else if (dtype == OCC_BF16) {
-        e = hipFuncSetAttribute((const void*)attention_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) { occ_set_error("occ_attention: cannot raise LDS limit: %s", hipGetErrorString(e)); return OCC_ELAUNCH; }
-        hipLaunchKernelGGL(attention_kernel<unsigned short>, grid, block, shm, s, (const unsigned short*)qkv, (unsigned short*)out, (int)T, (int)H, (int)hd, (long long)ld_qkv, (long long)ld_out, scale, qsplit);
-    } else { occ_set_error("occ_attention: dtype must be f32 or bf16"); return OCC_EUNSUPPORTED; }
-    OCC_LAUNCH_CHECK("occ_attention");
-    return OCC_OK;
+    return attention_f32_arith(qkv, out, dtype, B, T, H, hd, ld_qkv, ld_out, scale, nullptr, s);
+}
+
+int occ_attention_varlen(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd, int64_t ld_qkv, int64_t ld_out,
+                         float scale, const int32_t* kv_len, void* stream) {
+    OCC_CHECK_ARG(qkv && out && kv_len, "occ_attention_varlen: null pointer");
+    OCC_CHECK_ARG(B >= 1 && T >= 1 && H >= 1 && hd >= 8 && hd <= 128 && T <= (1 << 20), "occ_attention_varlen: bad shape");
+    OCC_CHECK_ARG(ld_qkv >= 3 * H * hd && ld_out >= H * hd, "occ_attention_varlen: leading dimensions too small");
+    return attention_f32_arith(qkv, out, dtype, B, T, H, hd, ld_qkv, ld_out, scale, kv_len, (hipStream_t)stream);
 }
 
 }  // extern "C"

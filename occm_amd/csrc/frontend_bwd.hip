@@ -855,21 +855,31 @@ static int lnb_impl(const void* dy, int dy_dtype, const void* x, int x_dtype, co
         return OCC_OK;
     }
     static const int lnb16 = getenv("OCC_LNB16") ? atoi(getenv("OCC_LNB16")) : 1;
-    long long blocks16 = occ_cdiv(rows, 16 * 4);        // >= 4 rows per wave
+    // C <= 512 (the conv stack): 16 waves of 128 registers; 512 < C <= 1024 (a transformer LayerNorm on the separate-pass route taken with
+    // residual dropout / layerdrop): 12 waves -- the 16-wave form of that width spilled 16 bytes per lane
+    const int wv = nit == 2 ? 12 : 16;
+    long long blocks16 = occ_cdiv(rows, wv * 4);        // >= 4 rows per wave
     if (blocks16 > lnb_blocks) blocks16 = lnb_blocks;
     const bool wide = lnb16 && rows >= 2048 && !(gelu && nit == 2) && nit <= 2;      // (the GELU form at C > 512 does not fit 128 registers)
     float* part = wide && scratch && scratch_floats >= blocks16 * 2 * C && ((uintptr_t)scratch & 15) == 0 ? scratch : nullptr;
-#define OCC_LNB_N(TD, TXX, G) do { if (nit == 1) { if (wide) OCC_LNB16(TD, TXX, 1, G); else OCC_LNB(TD, TXX, 1, G); } else if (nit == 2) { if (wide) OCC_LNB16(TD, TXX, 2, G); else OCC_LNB(TD, TXX, 2, G); } \
-                                   else if (nit == 3) OCC_LNB(TD, TXX, 3, false); else OCC_LNB(TD, TXX, 4, false); } while (0)
+#define OCC_LNB16W(TD, TXX, N, G, W) hipLaunchKernelGGL((layernorm_bwd16_kernel<TD, TXX, N, G, W>), dim3((unsigned)blocks16), dim3(64 * W), 0, s, (const TD*)dy, (const TXX*)x, gamma, beta, dres, dx, (unsigned short*)dx_bf16, bm, dgamma, dbeta, (long long)rows, (int)C, eps, part, LnbExtra{nullptr, nullptr, nullptr, 0})
+    // (the GELU form exists at C <= 512 only: no wide instantiation of it at NIT = 2)
+#define OCC_LNB_NG(TD, TXX) do { if (nit == 1) { if (wide) OCC_LNB16W(TD, TXX, 1, true, 16); else OCC_LNB(TD, TXX, 1, true); } else if (nit == 2) OCC_LNB(TD, TXX, 2, true); \
+                                 else if (nit == 3) OCC_LNB(TD, TXX, 3, false); else OCC_LNB(TD, TXX, 4, false); } while (0)
+#define OCC_LNB_NN(TD, TXX) do { if (nit == 1) { if (wide) OCC_LNB16W(TD, TXX, 1, false, 16); else OCC_LNB(TD, TXX, 1, false); } \
+                                 else if (nit == 2) { if (wide) OCC_LNB16W(TD, TXX, 2, false, 12); else OCC_LNB(TD, TXX, 2, false); } \
+                                 else if (nit == 3) OCC_LNB(TD, TXX, 3, false); else OCC_LNB(TD, TXX, 4, false); } while (0)
     const bool df = dy_dtype == OCC_F32, xf = x_dtype == OCC_F32;
     if (gelu) {
-        if (df && xf) OCC_LNB_N(float, float, true); else if (df) OCC_LNB_N(float, unsigned short, true);
-        else if (xf) OCC_LNB_N(unsigned short, float, true); else OCC_LNB_N(unsigned short, unsigned short, true);
+        if (df && xf) OCC_LNB_NG(float, float); else if (df) OCC_LNB_NG(float, unsigned short);
+        else if (xf) OCC_LNB_NG(unsigned short, float); else OCC_LNB_NG(unsigned short, unsigned short);
     } else {
-        if (df && xf) OCC_LNB_N(float, float, false); else if (df) OCC_LNB_N(float, unsigned short, false);
-        else if (xf) OCC_LNB_N(unsigned short, float, false); else OCC_LNB_N(unsigned short, unsigned short, false);
+        if (df && xf) OCC_LNB_NN(float, float); else if (df) OCC_LNB_NN(float, unsigned short);
+        else if (xf) OCC_LNB_NN(unsigned short, float); else OCC_LNB_NN(unsigned short, unsigned short);
     }
-#undef OCC_LNB_N
+#undef OCC_LNB_NG
+#undef OCC_LNB_NN
+#undef OCC_LNB16W
 #undef OCC_LNB16
 #undef OCC_LNB
     if (part) hipLaunchKernelGGL(layernorm_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(2 * C, 64)), dim3(256), 0, s, part, (int)blocks16, (int)C, dgamma, dbeta, (float*)nullptr, 2);

@@ -742,8 +742,17 @@ class AModel(AliasGuard, torch.nn.Module):
         self.param_set = attach_parameters(self, self.backend)
         self.dropout_masks = None      # None: draw masks on the device; {}: every back-end dropout off (the p = 0 of a parity run)
 
-    def forward(self, x, masks=None):
+    supports_lengths = True
+
+    def forward(self, x, masks=None, lengths=None):
+        """lengths (evaluation only, not in the reference): sample counts of a ZERO-PADDED batch of unequal utterances.  The front-end runs the
+        whole batch with key masks (``XlsrFrontend.forward``); the back-end -- whose pooling, graph sizes and top-k counts depend on the
+        frame count -- runs once per distinct frame count on the un-padded rows.  Row b of the result equals ``forward(x[b:b+1, :lengths[b]])``."""
         x = x.squeeze(-1) if x.dim() == 3 else x
+        if lengths is not None:
+            if self.training:
+                raise OccError("lengths (masked batches) are an evaluation feature: call model.eval() first")
+            return self._forward_lengths(x, [int(v) for v in lengths])
         feats = self.ssl_model.extract_feat(x)
         masks = self.dropout_masks if masks is None else masks
         be = self.backend
@@ -759,6 +768,17 @@ class AModel(AliasGuard, torch.nn.Module):
             return (d,)
 
         return run_engine(self.param_set, lambda f: be.forward(f, train=True, masks=masks), bwd, feats)
+
+    def _forward_lengths(self, x, lengths):
+        with torch.no_grad():
+            feats = self.ssl_model.extract_feat(x, lengths=lengths)
+            fr = [xlsr_mod.n_frames(v) for v in lengths]
+            emb = torch.empty(len(fr), 160, device=feats.device); out = torch.empty(len(fr), 2, device=feats.device)
+            for T in sorted(set(fr)):
+                idx = torch.tensor([i for i, t in enumerate(fr) if t == T], device=feats.device)
+                e, o = self.backend.forward(feats[idx, :T].contiguous(), train=False)
+                emb[idx] = e; out[idx] = o
+        return emb, out
 
     def backward(self, demb, dlogits):
         return self.backend.backward(demb, dlogits)

@@ -160,9 +160,15 @@ class XlsrFrontend(torch.nn.Module):
             self._ws[key] = self._ws.pop(key)          # most recently used last
         return self._ws[key]
 
-    def forward(self, wav, out_dtype=None, taps=None, slot=0, out=None):
+    def forward(self, wav, out_dtype=None, taps=None, slot=0, out=None, lengths=None):
         """wav f32 [B,L] on the GPU -> [B,T,dim] (dtype = out_dtype or the compute dtype).  ``slot`` selects an independent
-        activation workspace so two half-batches can run concurrently on two streams; ``out`` is an optional destination."""
+        activation workspace so two half-batches can run concurrently on two streams; ``out`` is an optional destination.
+
+        lengths (optional, samples per utterance of a ZERO-PADDED batch; scoring in length-sorted batches instead of the reference's
+        one-utterance loop, oc_classifier.py:182-186): rows [0, n_frames(lengths[b])) of utterance b then equal its un-padded
+        single-utterance result -- the un-padded conv stack never reads past a frame's own 400 samples, the projected features of the
+        pad frames are zeroed before the positional conv (which sees zeros there in the un-padded run too) and attention masks the pad
+        keys (occ_attention_varlen); every other layer is row-wise.  Rows past an utterance's frame count are not meaningful."""
         cfg, w, dt = self.cfg, self.w, self.dtype
         dst = out
         if wav.dim() == 3:
@@ -171,6 +177,13 @@ class XlsrFrontend(torch.nn.Module):
         B, L = wav.shape
         ws = self._workspace(B, L, slot)
         Ts, T, M = ws["Ts"], ws["T"], ws["M"]
+        kv_len = None
+        if lengths is not None:
+            fr = [n_frames(int(v)) for v in lengths]
+            if len(fr) != B or min(fr) < 1 or max(fr) > T:
+                raise OccError("lengths must give, per utterance, a sample count between one frame's worth and the padded length")
+            if min(fr) < T:
+                kv_len = torch.tensor(fr, dtype=torch.int32, device=self.device)
         code = dtype_code(ws["h"])
         D = cfg.dim
         # conv block 0 fused with its LayerNorm + GELU
@@ -198,6 +211,11 @@ class XlsrFrontend(torch.nn.Module):
         inner = xpad.data_ptr() + half * D * es
         pmap = rowmap(T, Tp * D, D)
         ops.gemm_raw(M, D, 512, ws["feat"], rowmap(M, 0, 512), w["proj.w"], 512, inner, pmap, code, code, bias=w["proj.b"])
+        if kv_len is not None:                                   # the positional conv pads with zeros past the utterance's last frame
+            xv = xpad.view(B, Tp, D)
+            for b, tb in enumerate(fr):
+                if tb < T:
+                    xv[b, half + tb: half + T].zero_()
         # grouped positional conv (+bias, GELU) added to the projection -> f32 residual stream
         G = cfg.pos_groups
         cg = D // G
@@ -212,7 +230,10 @@ class XlsrFrontend(torch.nn.Module):
         for i in range(cfg.layers):
             ops.layernorm(x, w["l%d.ln1.g" % i], w["l%d.ln1.b" % i], out=ws["h"])
             ops.linear(ws["h"], w["l%d.qkv.w" % i], w["l%d.qkv.b" % i], out=ws["qkv"])
-            ops.attention(ws["qkv"], B, T, cfg.heads, hd, hd ** -0.5, out=ws["att"])
+            if kv_len is not None:
+                ops.attention_varlen(ws["qkv"], B, T, cfg.heads, hd, hd ** -0.5, kv_len, out=ws["att"])
+            else:
+                ops.attention(ws["qkv"], B, T, cfg.heads, hd, hd ** -0.5, out=ws["att"])
             ops.gemm_raw(M, D, D, ws["att"], xmap, w["l%d.o.w" % i], D, x, xmap, OCC_F32, code, bias=w["l%d.o.b" % i],
                          R=x, r_map=xmap, r_dtype=OCC_F32)
             ops.layernorm(x, w["l%d.ln2.g" % i], w["l%d.ln2.b" % i], out=ws["h"])
@@ -277,19 +298,22 @@ class SSLModel(torch.nn.Module):
             # ``optim.Adam(aasist.parameters())`` (oc_training.py:324) holds XLS-R too
             self.param_set = attach_parameters(self.model, self.model)
 
-    def extract_feat(self, input_data):
-        """sslassist.py:31-49 / xlsr.py:39-48.  Frozen engine: a plain forward.  Fine-tuning engine in training mode: fairseq's
+    def extract_feat(self, input_data, lengths=None):
+        """sslassist.py:31-49 / xlsr.py:39-48.  ``lengths`` (not in the reference): sample counts of a zero-padded batch, see
+        ``XlsrFrontend.forward`` -- deterministic forward only (frozen engine, or a fine-tuning engine in eval mode).  Frozen engine: a plain forward.  Fine-tuning engine in training mode: fairseq's
         train-mode forward (dropouts / layerdrop per ``train_cfg``), taped for ``loss.backward()`` through
         ``autograd_bridge.EngineFunction``; in eval mode the deterministic forward."""
         x = input_data[:, :, 0] if input_data.dim() == 3 else input_data
         eng = self.model
         if not self.finetune:
             with torch.no_grad():
-                return eng.forward(x, out_dtype=torch.float32)
+                return eng.forward(x, out_dtype=torch.float32, lengths=lengths)
         eng.sync_operands()
         if not eng.training:                   # fairseq decides on the inner model's flag (``ssl.train()`` / ``aasist.train()`` set it)
             with torch.no_grad():
-                return eng.forward(x, out_dtype=torch.float32)
+                return eng.forward(x, out_dtype=torch.float32, lengths=lengths)
+        if lengths is not None:
+            raise OccError("lengths (masked batches) are an evaluation feature: the reference trains on zero-padded groups un-masked (oc_training.py:244-249)")
 
         def bwd(grads, needs):
             eng.backward(grads[0].contiguous().float())
@@ -297,8 +321,8 @@ class SSLModel(torch.nn.Module):
 
         return run_engine(self.param_set, lambda w: eng.forward_train(w.to(eng.device, torch.float32).contiguous()), bwd, x)
 
-    def forward(self, input_data):
-        return self.extract_feat(input_data)
+    def forward(self, input_data, lengths=None):
+        return self.extract_feat(input_data, lengths=lengths)
 
     def full_state_dict(self):
         """Every tensor of the loaded checkpoint under its fairseq name: the path's tensors (the trained values when fine-tuning) plus
@@ -1172,7 +1196,9 @@ class XlsrFullFineTuner(XlsrFineTuner):
             self._drop_bwd("in", dx, dx, self._p("dropout_input"))
         check(lib().occ_cast(ptr(dx), OCC_F32, ptr(tr["dxb"]), bfc, M * D, stream_ptr()), "occ_cast")      # dx changed since its bf16 copy was made
         self._wgrad(tr["dxb"], cv["lnfeat"], D, 512, M, "proj.w", "proj.b", c_is_zero=cleared)
-        ops.gemm_raw(M, 512, D, dx, xm, self.wT["proj.w"], D, cv["dln"], rowmap(M, 0, 512), bfc, OCC_AF32_WBF16)
+        # (the bf16 copy made for the weight gradient above is also this GEMM's operand: the f32-operand kernel rounds to bf16 on its way
+        # into LDS anyway, spills, and runs at a third of the eight-phase kernel's rate)
+        ops.gemm_raw(M, 512, D, tr["dxb"], xm, self.wT["proj.w"], D, cv["dln"], rowmap(M, 0, 512), bfc, bfc)
         ops.layernorm_bwd_ex(cv["dln"], cv["act"][6].view(M, 512), w["ln.g"], None, None, None, cv["dact"][6].view(M, 512), None, self.mg["ln.g"], self.mg["ln.b"], gelu=False)
         # fairseq scales the gradient that enters the conv feature extractor (GradMultiply, feature_grad_mult; 0 = extractor not trained)
         fgm = self.train_cfg.feature_grad_mult

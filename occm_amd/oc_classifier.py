@@ -63,18 +63,24 @@ def canonical_len(T):
     return (T - 1) * 320 + 400
 
 
-def embed_dataset(model, dataloader, device, batch_size=1, rank=0, world=1):
+PAD_FRAMES = 16          # masked batches: utterances whose frame counts fall into the same 16-frame band share a batch (<= 8 % padding at 4 s)
+
+
+def embed_dataset(model, dataloader, device, batch_size=1, rank=0, world=1, masked=None):
     """(emb [N,160] (AASIST) or [N,128] (SE-ResNet34), logits [N,2]) of every utterance, in dataset order.
 
     world > 1 (one process per GPU, torch.distributed initialised): rank r embeds the utterances whose position p has p % world == r
     -- the loader must then be built over ``shard_dataset(dataset, rank, world)`` -- and a sum all-reduce of the zero-initialised
     result tensors gives every rank the whole set ("shard the file list, all-gather the embeddings").
 
-    batch_size 1 is the reference's loop (oc_classifier.py:182-186, 243-265: one utterance per forward).  batch_size > 1 buckets by
-    frame count: utterances with the same number of frames, cropped to that count's canonical length, form one batch, so no padding
-    enters any layer and no key mask is needed -- per-utterance results differ from the one-at-a-time loop only through the GEMM
-    kernels picked for a different row count (summation order).  Buckets fill as the loader delivers utterances; at most
-    (#distinct frame counts in flight) x batch_size waveforms are held."""
+    batch_size 1 is the reference's loop (oc_classifier.py:182-186, 243-265: one utterance per forward).  batch_size > 1 batches
+    utterances of SIMILAR length: those whose frame counts fall into one band of PAD_FRAMES frames are cropped to the
+    samples their frames depend on, zero-padded to the longest of the batch and run through the front-end together with key masks
+    (``model(x, lengths=...)``: the positional conv sees zeros past each utterance's end and attention ignores the pad keys, as in the
+    un-padded run); the back-end runs per distinct frame count.  Per-utterance results differ from the one-at-a-time loop only through
+    the GEMM kernels picked for a different row count (summation order).  masked=False (or a model without ``supports_lengths``) falls
+    back to batches of EQUAL frame count, which need no mask at all.  Buckets fill as the loader delivers utterances; at most
+    (#bands in flight) x batch_size waveforms are held."""
     model.eval()
     ds = dataloader.dataset
     n_local = len(ds)
@@ -82,10 +88,20 @@ def embed_dataset(model, dataloader, device, batch_size=1, rank=0, world=1):
     width = int(getattr(model, "emb_dim", 160))              # AASIST: 160 (5 x 32 readouts); SE-ResNet34: 128
     embs, logits = torch.zeros(n, width, device=device), torch.zeros(n, 2, device=device)
     pending = {}
+    if masked is None:
+        masked = bool(getattr(model, "supports_lengths", False))
+    masked = masked and batch_size > 1
 
     def flush(items):
         idxs = torch.tensor([i * world + rank if world > 1 else i for i, _ in items], device=device)
-        emb, out = model(torch.stack([w for _, w in items]).to(device))
+        lens = [w.numel() for _, w in items]
+        if masked and min(lens) != max(lens):
+            x = torch.zeros(len(items), max(lens))
+            for j, (_, w) in enumerate(items):
+                x[j, : w.numel()] = w
+            emb, out = model(x.to(device), lengths=lens)
+        else:
+            emb, out = model(torch.stack([w for _, w in items]).to(device))
         embs[idxs] = emb.float(); logits[idxs] = out.float()
 
     pos = 0
@@ -98,13 +114,20 @@ def embed_dataset(model, dataloader, device, batch_size=1, rank=0, world=1):
                     T = n_frames(row.numel())
                     if T < 1:
                         raise ValueError("utterance %d: %d samples are too short for the conv stack" % (pos, row.numel()))
-                    bucket = pending.setdefault(T, [])
+                    key = (T - 1) // PAD_FRAMES if masked else T
+                    bucket = pending.setdefault(key, [])
                     bucket.append((pos, row[:canonical_len(T)]))
                     if len(bucket) == batch_size:
-                        flush(pending.pop(T))
+                        flush(pending.pop(key))
                 pos += 1
-        for T in sorted(pending):
-            flush(pending[T])
+        left = [it for key in sorted(pending) for it in pending[key]]
+        if masked:                                             # the partly filled bands, shortest first, in batches of neighbours
+            left.sort(key=lambda it: it[1].numel())
+            for i in range(0, len(left), batch_size):
+                flush(left[i:i + batch_size])
+        else:
+            for key in sorted(pending):
+                flush(pending[key])
     if pos != n_local:
         raise RuntimeError("loader delivered %d of %d utterances" % (pos, n_local))
     if world > 1:
@@ -142,9 +165,21 @@ class ExtractorEncoder:
         self.extractor.eval(); self.encoder.eval()
         return self
 
-    def __call__(self, data):
-        feats = self.extractor(data)
-        return self.encoder(feats.float().unsqueeze(1))
+    supports_lengths = True
+
+    def __call__(self, data, lengths=None):
+        if lengths is None:
+            feats = self.extractor(data)
+            return self.encoder(feats.float().unsqueeze(1))
+        # zero-padded batch of unequal utterances: masked front-end, the encoder once per distinct frame count (its pooling depends on it)
+        feats = self.extractor(data, lengths=lengths).float()
+        fr = [n_frames(int(v)) for v in lengths]
+        com = torch.empty(len(fr), self.emb_dim, device=feats.device); des = torch.empty(len(fr), 2, device=feats.device)
+        for T in sorted(set(fr)):
+            idx = torch.tensor([i for i, t in enumerate(fr) if t == T], device=feats.device)
+            c, d = self.encoder(feats[idx, :T].contiguous().unsqueeze(1))
+            com[idx] = c; des[idx] = d
+        return com, des
 
 
 def create_reference_embedding(extractor, encoder, dataloader, device, cache=True, batch_size=1, rank=0, world=1):
@@ -216,7 +251,8 @@ def main(argv=None):
     parser.add_argument("--eval_protocol_file", type=str, default="/datab/Dataset/ASVspoof/LA/ASVspoof_LA_cm_protocols/ASVspoof2019.LA.cm.eval.trl.txt")
     parser.add_argument("--eval_dataset_dir", type=str, default="/datab/Dataset/ASVspoof/LA/ASVspoof2019_LA_eval/flac")
     parser.add_argument("--two_class", action="store_true", help="score with the bona-fide logit (score_eval_set_2c2)")
-    parser.add_argument("--batch_size", type=int, default=1, help="1 = the reference's one-utterance loop; > 1 = batches of utterances with equal frame count")
+    parser.add_argument("--batch_size", type=int, default=1, help="1 = the reference's one-utterance loop; > 1 = batches of utterances of similar length, zero-padded "
+                        "to the longest, with key masks in the front-end (each utterance's result equals its one-at-a-time result)")
     parser.add_argument("--num_workers", type=int, default=0)
     parser.add_argument("--ssl_dtype", choices=["f32", "bf16"], default="f32",
                         help="arithmetic of the XLS-R front-end and the AASIST GEMMs: f32 (default) = exact-f32 MFMA, the path that meets the 1e-3 "

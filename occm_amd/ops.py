@@ -123,6 +123,18 @@ def attention(qkv, B, T, H, hd, scale, out=None, lse=None):
     return out
 
 
+def attention_varlen(qkv, B, T, H, hd, scale, kv_len, out=None):
+    """Attention over a zero-padded batch: kv_len int32 [B] (device) = valid frames per utterance; keys at or past it are masked, so the
+    first kv_len[b] rows of utterance b equal its un-padded single-utterance result (f32 arithmetic, storage f32 or bf16)."""
+    _dev(qkv)
+    D = H * hd
+    assert qkv.shape == (B * T, 3 * D) and qkv.is_contiguous() and kv_len.dtype == torch.int32 and kv_len.numel() == B
+    if out is None:
+        out = torch.empty(B * T, D, device=qkv.device, dtype=qkv.dtype)
+    check(lib().occ_attention_varlen(ptr(qkv), ptr(out), dtype_code(qkv), B, T, H, hd, 3 * D, D, float(scale), ptr(kv_len), stream_ptr()), "occ_attention_varlen")
+    return out
+
+
 def attention_bwd(qkv, o, dout, lse, B, T, H, hd, scale, dqkv=None):
     D = H * hd
     if dqkv is None:

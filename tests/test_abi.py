@@ -44,7 +44,10 @@ _NO_SCRATCH = ["gemm_bf16_dma_kernelILi128ELb0ELi128", "gemm_bf16_dma_kernelILi1
                # round 3: this round's hot kernels (the eight-phase GEMMs in all formats, the weight-gradient kernels, attention backward incl.
                # its dropout form, the fused LayerNorm backward of the transformer layers and the conv stack's LayerNorm+GELU backward)
                "gemm_p8_kernel", "gemm_tn_p8_kernel", "gemm_tn_p8_pair_kernel", "attention_bwd2_kernelILi64ELb0", "attention_bwd2_kernelILi80ELb0", "attention_bwd2_kernelILi64ELb1", "layernorm_bwd16_kernelItfLi2ELb0ELi12ELb1",
-               "layernorm_bwd16_kernelItfLi3ELb0ELi8ELb1", "layernorm_bwd16_kernelIttLi1ELb1", "layernorm_kernelIftLi2ELb1", "attention_mfma_long_kernel"]
+               "layernorm_bwd16_kernelItfLi3ELb0ELi8ELb1", "layernorm_bwd16_kernelIttLi1ELb1", "layernorm_kernelIftLi2ELb1", "attention_mfma_long_kernel",
+               # round 4: the separate-pass LayerNorm backward at C = 1024 (the route residual dropout / layerdrop take: 12 waves, the 16-wave
+               # form spilled) and the four-wave GEMM
+               "Li2ELb0ELi12ELb0EEEv", "gemm_q4_kernel"]
 
 
 def test_hot_kernels_do_not_spill():

@@ -78,7 +78,7 @@ def test_lcnn_matches_reference_vectors(tag, shape, seed):
     m.train()
     m.backend.zero_grad()
     y = m(x.cuda(), masks={})
-    np.testing.assert_allclose(y.cpu().numpy(), GL["train_" + tag], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), GL["train_" + tag], rtol=5e-4, atol=5e-5)
     m.backward(torch.tensor(GL["train_wgt_" + tag]).cuda())
     sd = m.state_dict()
     for k in ("layer2.2.running_mean", "layer2.2.running_var", "layer3.2.running_mean", "layer3.2.running_var"):
@@ -115,7 +115,7 @@ def test_lcnn_dropout_masks_feature_gradient_and_state_dict_against_oracle():
     assert list(m.state_dict().keys()) == list(lcnn_ref.param_shapes().keys())          # the reference's keys, in its order (gen_golden loaded them strict)
     m.train(); m.backend.zero_grad()
     y = m(x.cuda(), masks=masks)
-    torch.testing.assert_close(y.cpu(), ref.detach(), rtol=5e-4, atol=5e-5)
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=5e-4, atol=5e-5)
     dx = m.backward(w.cuda(), want_dfeats=True)
     gd = m.backend.grad_dict()
     gmax = max(float(v.grad.abs().max()) for v in q.values() if torch.is_tensor(v) and v.grad is not None)
@@ -159,9 +159,9 @@ def test_occm_dual_branch_forward_backward_against_oracle():
     m.train()
     m.senet34_branch.backend.zero_grad(); m.lcnn_branch.backend.zero_grad()
     (c2, d2), l2 = m.forward_features(feats.cuda(), masks={})
-    torch.testing.assert_close(c2.cpu(), com.detach(), rtol=1e-3, atol=1e-4)
-    torch.testing.assert_close(d2.cpu(), des.detach(), rtol=1e-3, atol=1e-4)
-    torch.testing.assert_close(l2.cpu(), lo.detach(), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(c2.detach().cpu(), com.detach(), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(d2.detach().cpu(), des.detach(), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(l2.detach().cpu(), lo.detach(), rtol=1e-3, atol=1e-4)
     dfe = m.backward(wc.cuda(), wd.cuda(), wl.cuda(), want_dfeats=True)
     torch.testing.assert_close(dfe.cpu(), fr.grad, rtol=5e-3, atol=5e-3 * float(fr.grad.abs().max()))
     keys = set(m.state_dict())

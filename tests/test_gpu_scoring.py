@@ -348,3 +348,77 @@ def test_scoring_300m_24_layers_f32_and_bf16_paths_vs_oracle_chain(tmp_path, mon
     # bounded at about twice that.  It does not meet north_star's 1e-3: that is why f32 is the scoring default.
     assert b16["max_abs_d_emb"] < 5.0 and b16["max_abs_d_distance"] < 2.0, b16
     assert b16["flipped_decisions"] <= 4 and b16["d_eer_percent"] <= 8.4, b16
+
+
+@pytest.mark.parametrize("T,H,hd,dt", [(50, 4, 64, torch.float32), (199, 16, 64, torch.float32), (343, 4, 64, torch.float32), (700, 2, 64, torch.float32),
+                                       (700, 2, 80, torch.float32), (1030, 1, 128, torch.float32), (420, 4, 64, torch.bfloat16)])
+def test_f32_attention_any_length_and_key_masks(T, H, hd, dt):
+    """occ_attention on the f32 scoring path used to stop at ~300 frames (K and V of a head in LDS); utterances of the ASVspoof eval lists
+    run to 13 s (650 frames).  The streaming kernel (keys in blocks of 64, online softmax) takes over beyond that, and occ_attention_varlen
+    masks the pad keys of a zero-padded batch: rows [0, len_b) of every utterance against torch's softmax attention of the un-padded rows."""
+    from occm_amd import ops
+    B, D = 3, H * hd
+    g = torch.Generator().manual_seed(T + hd)
+    qkv = torch.randn(B * T, 3 * D, generator=g).to(dt).cuda()
+    lens = [T, max(1, T // 3), T - 7]
+
+    def ref(b, n):
+        x = qkv.view(B, T, 3, H, hd)[b, :n].double()
+        q, k, v = x[:, 0].transpose(0, 1), x[:, 1].transpose(0, 1), x[:, 2].transpose(0, 1)           # [H, n, hd]
+        p = torch.softmax(q @ k.transpose(1, 2) * hd ** -0.5, dim=-1)
+        return (p @ v).transpose(0, 1).reshape(n, D)
+
+    tol = dict(rtol=1e-4, atol=2e-5) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    full = ops.attention(qkv, B, T, H, hd, hd ** -0.5).view(B, T, D)
+    for b in range(B):
+        torch.testing.assert_close(full[b].double(), ref(b, T), **tol)
+    kv = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = ops.attention_varlen(qkv, B, T, H, hd, hd ** -0.5, kv).view(B, T, D)
+    assert bool(torch.isfinite(out.float()).all())                                                     # pad rows: not meaningful, but never NaN
+    for b, n in enumerate(lens):
+        torch.testing.assert_close(out[b, :n].double(), ref(b, n), **tol)
+
+
+def test_masked_batches_of_unequal_utterances_equal_one_at_a_time(tmp_path, monkeypatch):
+    """oc_classifier --batch_size N (length-bucketed batches WITH masks): 14 utterances of 13 distinct frame counts between 1.1 s
+    and 7.2 s (the longest past the whole-head limit of the f32 attention kernel), two layers, f32.  Every utterance's embedding and logits in
+    masked batches of 4 must equal the reference's one-utterance loop; the un-masked padded forward must NOT (the mask is doing something)."""
+    from oracle import aasist_ref, xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.models import xlsr
+    from occm_amd.models.sslassist import AModel
+    from occm_amd.oc_classifier import ASVDataset, embed_dataset, n_frames
+    from torch.utils.data import DataLoader
+    monkeypatch.chdir(tmp_path)
+    d = tmp_path / "audio"; d.mkdir()
+    lens = [17600, 18000, 19000, 20100, 21000, 22222, 23000, 24000, 64000, 64000, 66000, 67000, 112000, 115000]
+    frames = [n_frames(L) for L in lens]
+    assert len(set(frames)) >= 12 and max(frames) > 340
+    for i, L in enumerate(lens):
+        _write_wav(str(d / f"U{i}.wav"), L, 300 + i)
+    (tmp_path / "eval.txt").write_text("\n".join(f"U{i}" for i in range(len(lens))) + "\n")
+    kw = dict(dim=1024, ffn=512, heads=16, layers=2)
+    rcfg, cfg = xlsr_ref.XlsrConfig(**kw), xlsr.XlsrConfig(**kw)
+    model = AModel(None, "cuda", ssl_cfg=cfg, ssl_dtype=torch.float32, ssl_state_dict=fill_like(xlsr_ref.param_shapes(rcfg), seed=3),
+                   backend_state_dict=fill_like(aasist_ref.param_shapes(), seed=0))
+    ev = DataLoader(ASVDataset(str(tmp_path / "eval.txt"), str(d), eval=True), batch_size=1, shuffle=False)
+    e1, l1 = embed_dataset(model, ev, "cuda", 1)
+    calls = []
+    fwd = model.forward
+    model.forward = lambda x, **kw_: (calls.append((tuple(x.shape), kw_.get("lengths"))), fwd(x, **kw_))[1]
+    e4, l4 = embed_dataset(model, ev, "cuda", 4)
+    model.forward = fwd
+    assert len(calls) <= 6 and any(c[1] is not None and len(set(c[1])) > 1 for c in calls), calls     # 14 utterances in at most 6 forwards, some ragged
+    torch.testing.assert_close(e4, e1, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(l4, l1, rtol=2e-4, atol=2e-4)
+    # the same padded batch WITHOUT the mask is a different function of the shorter utterance
+    model.eval()
+    from occm_amd.data_utils_SSL import load_audio
+    a, b = [torch.tensor(load_audio(str(d / f"U{i}.wav"))[0]) for i in (0, 7)]
+    x = torch.zeros(2, b.numel()); x[0, : a.numel()] = a; x[1] = b
+    with torch.no_grad():
+        em, _ = model(x.cuda(), lengths=[a.numel(), b.numel()])
+        feats = model.ssl_model.extract_feat(x.cuda())[:1, : n_frames(a.numel())].contiguous()
+        eu, _ = model.backend.forward(feats, train=False)
+    torch.testing.assert_close(em[0], e1[0], rtol=2e-4, atol=2e-4)
+    assert float((eu[0] - e1[0]).abs().max()) > 1e-2

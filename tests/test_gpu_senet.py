@@ -78,8 +78,8 @@ def test_senet_matches_reference_outputs(tag, shape, seed):
     np.testing.assert_allclose(des.cpu().numpy(), GS["eval_des_" + tag], rtol=1e-3, atol=1e-3)
     net.train()
     com, des = net(x)
-    np.testing.assert_allclose(com.cpu().numpy(), GS["train_com_" + tag], rtol=1e-3, atol=1e-3)
-    np.testing.assert_allclose(des.cpu().numpy(), GS["train_des_" + tag], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(com.detach().cpu().numpy(), GS["train_com_" + tag], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(des.detach().cpu().numpy(), GS["train_des_" + tag], rtol=1e-3, atol=1e-3)
 
 
 def test_senet_state_dict_round_trip_and_running_stats():
