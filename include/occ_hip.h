@@ -25,7 +25,10 @@ enum occ_status { OCC_OK = 0, OCC_EINVAL = -1, OCC_ELAUNCH = -2, OCC_EUNSUPPORTE
 enum occ_dtype { OCC_F32 = 0, OCC_BF16 = 1, OCC_F64 = 2, OCC_F32_AS_BF16 = 3 /* occ_gemm ab_dtype only: f32 operands in memory, rounded to bf16 on the way into LDS, bf16 MFMA */,
                  OCC_AF32_WBF16 = 4 /* occ_gemm ab_dtype only: A f32 in memory (rounded to bf16 while staged), W bf16 */,
                  OCC_FP8_E4M3 = 5, OCC_FP8_E5M2 = 6 /* OCP 8-bit floats (e4m3fn / e5m2), one byte per element: occ_fp8_quantize output;
-                    as occ_gemm ab_dtype: A in that format, W e4m3, products on v_mfma_scale_f32_16x16x128_f8f6f4, f32 accumulate */ };
+                    as occ_gemm ab_dtype: A in that format, W e4m3, products on v_mfma_scale_f32_16x16x128_f8f6f4, f32 accumulate */,
+                 OCC_F32X3 = 7 /* occ_gemm ab_dtype only: f32 operands in memory, each split into bf16 hi + lo while staged; three bf16 MFMAs per
+                    block (Wh.Xh + Wl.Xh + Wh.Xl, f32 accumulate): products exact to 2^-16 relative at 3/16 of the exact-f32 MFMA's cycles --
+                    the accurate-and-fast arithmetic of the scoring path (K %% 8 == 0) */ };
 enum occ_act { OCC_ACT_NONE = 0, OCC_ACT_GELU = 1, OCC_ACT_SELU = 2, OCC_ACT_RELU = 3, OCC_ACT_TANH = 4,
                OCC_ACT_GELU_GRAD = 5 /* occ_gemm epilogue: (acc+bias) * gelu'(aux) */,
                /* The same pair with the derivative computed ONCE, in the forward epilogue, where the exponential is already at hand:

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("OCC_LIB") or "libocc_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "occ_hip.h")
 
-OCC_F32, OCC_BF16, OCC_F64, OCC_F32_AS_BF16, OCC_AF32_WBF16, OCC_FP8_E4M3, OCC_FP8_E5M2 = 0, 1, 2, 3, 4, 5, 6
+OCC_F32, OCC_BF16, OCC_F64, OCC_F32_AS_BF16, OCC_AF32_WBF16, OCC_FP8_E4M3, OCC_FP8_E5M2, OCC_F32X3 = 0, 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_GELU, ACT_SELU, ACT_RELU, ACT_TANH, ACT_GELU_GRAD, ACT_GELU_KEEP_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6, 7
 
 

@@ -831,6 +831,9 @@ static int attention_f32_arith(const void* qkv, void* out, int dtype, int64_t B,
     return OCC_OK;
 }
 
+int occ_conv0_mfma_launch(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta, void* out, long long B, long long L,
+                          long long Tout, long long stride, float eps, hipStream_t s);     // conv0_mfma.hip
+
 extern "C" {
 
 int occ_layernorm(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int64_t rows, int64_t C,
@@ -867,10 +870,19 @@ int occ_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const
     OCC_CHECK_ARG(C == 512, "occ_conv0_ln_gelu: C must be 512 (got %ld)", (long)C);
     OCC_CHECK_ARG(k >= 1 && k <= C0_MAXK && stride >= 1 && stride <= 16, "occ_conv0_ln_gelu: k in [1,16], stride in [1,16]");
     OCC_CHECK_ARG(B >= 1 && B < 65536 && L >= k && Tout == (L - k) / stride + 1, "occ_conv0_ln_gelu: Tout must equal (L-k)/stride+1");
+    hipStream_t s = (hipStream_t)stream;
+    // bf16 output of the XLS-R geometry: the matrix-core form (conv0_mfma.hip: split-operand bf16 MFMA, f32-grade products).  The f32
+    // parity path and other tap counts keep the VALU kernel below.  OCC_CONV0_MFMA=0 switches back (A/B).
+    static const int c0_mfma = getenv("OCC_CONV0_MFMA") ? atoi(getenv("OCC_CONV0_MFMA")) : 1;
+    if (c0_mfma && out_dtype == OCC_BF16 && k == 10 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(gamma) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(beta) & 15) == 0) {
+        occ_conv0_mfma_launch(wav, w, bias, gamma, beta, out, B, L, Tout, stride, eps, s);
+        OCC_LAUNCH_CHECK("occ_conv0_ln_gelu(mfma)");
+        return OCC_OK;
+    }
     const dim3 grid((unsigned)occ_cdiv(Tout, C0_FRAMES), (unsigned)B), block(256);
     const int kt = k <= 10 ? 10 : C0_MAXK;
     const size_t shm = ((C0_FRAMES - 1) * stride + kt) * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
 #define OCC_C0_LAUNCH(TO, KT) hipLaunchKernelGGL((conv0_ln_gelu_kernel<TO, KT>), grid, block, shm, s, wav, w, bias, gamma, beta, (TO*)out, (int)L, (int)Tout, (int)k, (int)stride, eps)
     if (out_dtype == OCC_F32) { if (kt == 10) OCC_C0_LAUNCH(float, 10); else OCC_C0_LAUNCH(float, C0_MAXK); }
     else if (out_dtype == OCC_BF16) { if (kt == 10) OCC_C0_LAUNCH(unsigned short, 10); else OCC_C0_LAUNCH(unsigned short, C0_MAXK); }

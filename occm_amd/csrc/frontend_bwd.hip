@@ -770,6 +770,10 @@ __global__ __launch_bounds__(256) void wn_bwd_apply_kernel(const float* __restri
 
 }  // namespace
 
+int occ_conv0_bwd_mfma_launch(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta, const void* dact, int dact_bf16,
+                              float* dw, float* dbias, float* dgamma, float* dbeta, long long B, long long L, long long Tout, long long stride, float eps,
+                              hipStream_t s);     // conv0_mfma.hip
+
 extern "C" {
 
 int occ_transpose_bf16_rows(const void* src, int src_dtype, const occ_rowmap* src_map, void* dst, int64_t rows, int64_t cols, int64_t ld_dst,
@@ -937,6 +941,14 @@ int occ_conv0_ln_gelu_bwd(const float* wav, const float* w, const float* bias, c
     OCC_CHECK_ARG(C == 512 && k >= 1 && k <= C0B_MAXK && stride >= 1 && stride <= 16 && B >= 1 && B < 65536 && Tout == (L - k) / stride + 1,
                   "occ_conv0_ln_gelu_bwd: bad shape");
     OCC_CHECK_ARG(dact_dtype == OCC_F32 || dact_dtype == OCC_BF16, "occ_conv0_ln_gelu_bwd: dact must be f32 or bf16");
+    // XLS-R geometry: the matrix-core form (conv0_mfma.hip).  OCC_CONV0_BWD_MFMA=0 switches back to the VALU kernel below (A/B).
+    static const int c0b_mfma = getenv("OCC_CONV0_BWD_MFMA") ? atoi(getenv("OCC_CONV0_BWD_MFMA")) : 1;
+    if (c0b_mfma && k == 10 && (reinterpret_cast<uintptr_t>(dact) & 15) == 0 && (reinterpret_cast<uintptr_t>(gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(beta) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(w) & 7) == 0) {
+        occ_conv0_bwd_mfma_launch(wav, w, bias, gamma, beta, dact, dact_dtype == OCC_BF16, dw, dbias, dgamma, dbeta, B, L, Tout, stride, eps, (hipStream_t)stream);
+        OCC_LAUNCH_CHECK("occ_conv0_ln_gelu_bwd(mfma)");
+        return OCC_OK;
+    }
     const int nsamp = (int)((C0B_FRAMES - 1) * stride + k);
     const size_t shm = ((size_t)((nsamp + 3) & ~3) + (size_t)512 * (k + 3)) * sizeof(float);
     const dim3 grid((unsigned)occ_cdiv(Tout, C0B_FRAMES), (unsigned)B), block(256);

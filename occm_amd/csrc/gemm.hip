@@ -23,6 +23,12 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float4 lo, const float4 hi) {
                       (unsigned)f32_to_bf16_bits(hi.z) | ((unsigned)f32_to_bf16_bits(hi.w) << 16));
 }
 
+// the lo parts of a hi / lo bf16 split of eight f32 values (hi = bf16(v) as pack_bf16x8 gives it, lo = bf16(v - hi))
+__device__ __forceinline__ uint4 pack_bf16x8_lo(const float4 lo, const float4 hi) {
+    auto r = [](float v) { return v - bf16_bits_to_f32(f32_to_bf16_bits(v)); };
+    return pack_bf16x8(make_float4(r(lo.x), r(lo.y), r(lo.z), r(lo.w)), make_float4(r(hi.x), r(hi.y), r(hi.z), r(hi.w)));
+}
+
 // TNT = 128: 2x2 waves, 64x64 per wave, 64 KiB LDS, 2 workgroups per CU.  TNT = 64 (narrow outputs: the back-ends' 32/64-channel
 // convolutions): 4x1 waves, 32x64 per wave, 48 KiB LDS, 3 workgroups per CU, no MFMA work on columns that do not exist.
 template <int MODE, int TNT = 128>
@@ -30,10 +36,14 @@ __global__ __launch_bounds__(THREADS, TNT == 128 ? 2 : 3) void gemm_kernel(const
     constexpr int NJ = TNT == 128 ? 4 : 2;      // 16-row blocks per wave
     constexpr int WPASS = TNT / 32;             // staging passes over the W rows
     constexpr bool BF16 = MODE != 0;            // MFMA flavour
+    // MODE 4 ("f32 x3"): f32 operands in memory, each split while staged into bf16 hi = bf16(v) and lo = bf16(v - hi); the product is
+    // three bf16 MFMAs per block, Wh.Xh + Wl.Xh + Wh.Xl (the dropped Wl.Xl term is 2^-16 relative): f32-grade results at 3/16 of
+    // the exact-f32 MFMA's cycles.  A slab is 32 K elements: chunks 0-3 of a row hold the hi parts, chunks 4-7 the lo parts.
+    constexpr bool SPLIT3 = MODE == 4;
     constexpr int ES = MODE == 1 ? 2 : 4;       // element size of X in memory (MODE 3: X f32, W bf16)
     constexpr int WES = (MODE == 1 || MODE == 3) ? 2 : 4;
     constexpr int CE = BF16 ? 8 : 4;            // K elements per 16-B LDS chunk
-    constexpr int SLAB_K = BF16 ? 64 : 32;      // K elements per slab
+    constexpr int SLAB_K = (BF16 && !SPLIT3) ? 64 : 32;      // K elements per slab
     __shared__ uint4 lds[2][(TM + TNT) * CHUNKS];   // [buffer][X rows, then W rows][row*8 + swizzled chunk]
 
     // ---- XCD-aware tile id: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
@@ -69,12 +79,22 @@ __global__ __launch_bounds__(THREADS, TNT == 128 ? 2 : 3) void gemm_kernel(const
 
     uint4 px[4], pw[WPASS];
     auto issue_loads = [&](int slab) {
-        const long long k0 = (long long)slab * SLAB_K + ch * CE;
+        const long long k0 = (long long)slab * SLAB_K + (SPLIT3 ? (ch & 3) : ch) * CE;
         long long kx = k0;
         if (a.nseg > 1) { const long long sg = k0 / a.seg_len; kx = sg * a.seg_stride + (k0 - sg * a.seg_len); }
         const bool ok = k0 < a.K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if constexpr (SPLIT3) {
+                if (ok) {
+                    const float4* xp = reinterpret_cast<const float4*>(Xg + xoff[i] + kx * ES);
+                    px[i] = ch < 4 ? pack_bf16x8(xp[0], xp[1]) : pack_bf16x8_lo(xp[0], xp[1]);
+                    if (i < WPASS) {
+                        const float4* wp = reinterpret_cast<const float4*>(Wg + woff[i % WPASS] + k0 * WES);
+                        pw[i % WPASS] = ch < 4 ? pack_bf16x8(wp[0], wp[1]) : pack_bf16x8_lo(wp[0], wp[1]);
+                    }
+                } else { px[i] = make_uint4(0, 0, 0, 0); if (i < WPASS) pw[i % WPASS] = px[i]; }
+            } else
             if constexpr (MODE == 2 || MODE == 3) {
                 if (ok) {
                     const float4* xp = reinterpret_cast<const float4*>(Xg + xoff[i] + kx * ES);
@@ -118,6 +138,30 @@ __global__ __launch_bounds__(THREADS, TNT == 128 ? 2 : 3) void gemm_kernel(const
     for (int slab = 0; slab < nslab; ++slab) {
         const int cur = slab & 1;
         if (slab + 1 < nslab) issue_loads(slab + 1);
+        if constexpr (SPLIT3) {
+            uint4 wh[4], wl[4], xh[NJ], xl[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = wn * 64 + i * 16 + fr;
+                wh[i] = lds[cur][TM * CHUNKS + rw * CHUNKS + (fq ^ (rw & 7))];
+                wl[i] = lds[cur][TM * CHUNKS + rw * CHUNKS + ((4 + fq) ^ (rw & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int rx = wm * (NJ * 16) + j * 16 + fr;
+                xh[j] = lds[cur][rx * CHUNKS + (fq ^ (rx & 7))];
+                xl[j] = lds[cur][rx * CHUNKS + ((4 + fq) ^ (rx & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wl[i]), *reinterpret_cast<bf16x8*>(&xh[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wh[i]), *reinterpret_cast<bf16x8*>(&xl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wh[i]), *reinterpret_cast<bf16x8*>(&xh[j]), acc[i][j], 0, 0, 0);
+                }
+        } else
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             uint4 wf[4], xf[NJ];
@@ -581,7 +625,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     OCC_CHECK_ARG(d->A && d->W && d->C, "occ_gemm: null operand");
     OCC_CHECK_ARG(d->M >= 1 && d->N >= 1 && d->K >= 1, "occ_gemm: bad shape M=%ld N=%ld K=%ld", (long)d->M, (long)d->N, (long)d->K);
     const bool fp8 = d->ab_dtype == OCC_FP8_E4M3 || d->ab_dtype == OCC_FP8_E5M2;
-    OCC_CHECK_ARG(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_F32 || d->ab_dtype == OCC_F32_AS_BF16 || d->ab_dtype == OCC_AF32_WBF16 || fp8,
+    OCC_CHECK_ARG(d->ab_dtype == OCC_BF16 || d->ab_dtype == OCC_F32 || d->ab_dtype == OCC_F32_AS_BF16 || d->ab_dtype == OCC_AF32_WBF16 || d->ab_dtype == OCC_F32X3 || fp8,
                   "occ_gemm: ab_dtype must be bf16, f32, f32-as-bf16, af32-wbf16 or fp8 (e4m3 / e5m2)");
     OCC_CHECK_ARG(!(d->act == OCC_ACT_GELU_GRAD && !d->aux), "occ_gemm: OCC_ACT_GELU_GRAD needs aux");
     if (d->act == OCC_ACT_GELU_KEEP_GRAD || d->act == OCC_ACT_MUL_AUX) {
@@ -786,6 +830,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     }
     else if (d->ab_dtype == OCC_F32_AS_BF16) hipLaunchKernelGGL(gemm_kernel<2>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else if (d->ab_dtype == OCC_AF32_WBF16) hipLaunchKernelGGL(gemm_kernel<3>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
+    else if (d->ab_dtype == OCC_F32X3) hipLaunchKernelGGL(gemm_kernel<4>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     else hipLaunchKernelGGL(gemm_kernel<0>, dim3((unsigned)total, (unsigned)ng), dim3(THREADS), 0, s, a);
     OCC_LAUNCH_CHECK("occ_gemm");
     return OCC_OK;

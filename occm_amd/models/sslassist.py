@@ -728,14 +728,14 @@ class AModel(AliasGuard, torch.nn.Module):
     deterministic synthetic filler because no checkpoint exists offline (the reference hard-codes a path, :24)."""
 
     def __init__(self, args=None, device="cuda", ssl_cfg=None, ssl_dtype=torch.bfloat16, ssl_state_dict=None, backend_state_dict=None, seed=0,
-                 backend_compute=None, finetune_ssl=False, ssl_cp_path=None, synthetic_ssl=False, ssl_train_cfg=None, ssl_model=None):
+                 backend_compute=None, finetune_ssl=False, ssl_cp_path=None, synthetic_ssl=False, ssl_train_cfg=None, ssl_model=None, ssl_f32_gemm="exact"):
         """ssl_model: a ready front-end module offering ``extract_feat(x) -> f32 [B,T,1024]`` to use instead of building ``SSLModel``
         (the parity tests pass a stub that hands seeded features through, exactly as the golden generator stubs the reference's)."""
         super().__init__()
         self.device = device
         self.ssl_model = ssl_model if ssl_model is not None else \
             SSLModel(device, cp_path=ssl_cp_path, state_dict=ssl_state_dict, cfg=ssl_cfg, dtype=ssl_dtype, seed=seed, finetune=finetune_ssl,
-                     synthetic=synthetic_ssl, train_cfg=ssl_train_cfg)
+                     synthetic=synthetic_ssl, train_cfg=ssl_train_cfg, f32_gemm=ssl_f32_gemm)
         if backend_compute is None:
             backend_compute = "bf16" if ssl_dtype == torch.bfloat16 else "f32"
         self.backend = AasistBackend(backend_state_dict, device=device, seed=seed, compute=backend_compute)

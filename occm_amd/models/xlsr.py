@@ -17,7 +17,7 @@ import os
 import torch
 
 from .. import ops
-from .._lib import ACT_GELU, ACT_GELU_GRAD, ACT_GELU_KEEP_GRAD, ACT_MUL_AUX, ACT_NONE, OCC_AF32_WBF16, OCC_BF16 as OCC_BF16_CODE, OCC_F32, OccError, dtype_code, require_gpu
+from .._lib import ACT_GELU, ACT_GELU_GRAD, ACT_GELU_KEEP_GRAD, ACT_MUL_AUX, ACT_NONE, OCC_AF32_WBF16, OCC_BF16 as OCC_BF16_CODE, OCC_F32, OCC_F32X3, OccError, dtype_code, require_gpu
 from ..autograd_bridge import attach_parameters, run_engine
 from ..ops import rowmap
 
@@ -84,11 +84,17 @@ class XlsrFrontend(torch.nn.Module):
     (``ssl_model.model.encoder.layers.0.fc1.weight`` ...), as the reference's module tree has them (sslassist.py:25-29); the frozen
     engine registers none (its operands are packed bf16 copies)."""
 
-    def __init__(self, params, cfg, device="cuda", dtype=torch.bfloat16):
+    def __init__(self, params, cfg, device="cuda", dtype=torch.bfloat16, f32_gemm="exact"):
+        """f32_gemm (dtype float32 only): "exact" = the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, the parity path); "x3" = every operand
+        split into bf16 hi + lo while it is staged and three bf16 MFMAs per block (OCC_F32X3): products exact to 2^-16 relative at 3/16 of
+        the cycles -- activations, LayerNorm, attention and accumulation stay f32 either way."""
         super().__init__()
         require_gpu()
         if dtype not in (torch.bfloat16, torch.float32):
             raise OccError("XlsrFrontend dtype must be bfloat16 or float32")
+        if f32_gemm not in ("exact", "x3"):
+            raise OccError("f32_gemm must be 'exact' or 'x3'")
+        self.f32_gemm = f32_gemm
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.out_dim = cfg.dim
         self._ws = {}
@@ -185,6 +191,7 @@ class XlsrFrontend(torch.nn.Module):
             if min(fr) < T:
                 kv_len = torch.tensor(fr, dtype=torch.int32, device=self.device)
         code = dtype_code(ws["h"])
+        ab = OCC_F32X3 if (code == OCC_F32 and self.f32_gemm == "x3") else code          # the GEMMs' arithmetic (storage stays `code`)
         D = cfg.dim
         # conv block 0 fused with its LayerNorm + GELU
         cur, nxt = ws["cA"], ws["cB"]
@@ -195,7 +202,7 @@ class XlsrFrontend(torch.nn.Module):
             Tout = Ts[i]
             out = nxt[: B * Tout * 512].view(B * Tout, 512)
             ops.gemm_raw(B * Tout, 512, k * 512, cur, rowmap(Tout, Tin * 512, s * 512), w["c%d.w" % i], k * 512,
-                         out, rowmap(B * Tout, 0, 512), code, code, bias=w["c%d.b" % i])
+                         out, rowmap(B * Tout, 0, 512), code, ab, bias=w["c%d.b" % i])
             ops.layernorm(out, w["c%d.g" % i], w["c%d.be" % i], gelu=True, out=out)
             cur, nxt = nxt, cur
             Tin = Tout
@@ -210,7 +217,7 @@ class XlsrFrontend(torch.nn.Module):
         es = xpad.element_size()
         inner = xpad.data_ptr() + half * D * es
         pmap = rowmap(T, Tp * D, D)
-        ops.gemm_raw(M, D, 512, ws["feat"], rowmap(M, 0, 512), w["proj.w"], 512, inner, pmap, code, code, bias=w["proj.b"])
+        ops.gemm_raw(M, D, 512, ws["feat"], rowmap(M, 0, 512), w["proj.w"], 512, inner, pmap, code, ab, bias=w["proj.b"])
         if kv_len is not None:                                   # the positional conv pads with zeros past the utterance's last frame
             xv = xpad.view(B, Tp, D)
             for b, tb in enumerate(fr):
@@ -220,7 +227,7 @@ class XlsrFrontend(torch.nn.Module):
         G = cfg.pos_groups
         cg = D // G
         x = ws["x"]
-        ops.gemm_raw(M, cg, cfg.pos_k * cg, xpad, pmap, w["pos.w"], cfg.pos_k * cg, x, rowmap(M, 0, D), OCC_F32, code,
+        ops.gemm_raw(M, cg, cfg.pos_k * cg, xpad, pmap, w["pos.w"], cfg.pos_k * cg, x, rowmap(M, 0, D), OCC_F32, ab,
                      bias=w["pos.b"], act=ACT_GELU, R=inner, r_map=pmap, r_dtype=code,
                      a_seg=(cfg.pos_k, cg, D), groups=(G, cg, cg * cfg.pos_k * cg, cg))
         if taps is not None:
@@ -229,16 +236,16 @@ class XlsrFrontend(torch.nn.Module):
         xmap = rowmap(M, 0, D)
         for i in range(cfg.layers):
             ops.layernorm(x, w["l%d.ln1.g" % i], w["l%d.ln1.b" % i], out=ws["h"])
-            ops.linear(ws["h"], w["l%d.qkv.w" % i], w["l%d.qkv.b" % i], out=ws["qkv"])
+            ops.linear(ws["h"], w["l%d.qkv.w" % i], w["l%d.qkv.b" % i], out=ws["qkv"], ab_dtype=ab)
             if kv_len is not None:
                 ops.attention_varlen(ws["qkv"], B, T, cfg.heads, hd, hd ** -0.5, kv_len, out=ws["att"])
             else:
                 ops.attention(ws["qkv"], B, T, cfg.heads, hd, hd ** -0.5, out=ws["att"])
-            ops.gemm_raw(M, D, D, ws["att"], xmap, w["l%d.o.w" % i], D, x, xmap, OCC_F32, code, bias=w["l%d.o.b" % i],
+            ops.gemm_raw(M, D, D, ws["att"], xmap, w["l%d.o.w" % i], D, x, xmap, OCC_F32, ab, bias=w["l%d.o.b" % i],
                          R=x, r_map=xmap, r_dtype=OCC_F32)
             ops.layernorm(x, w["l%d.ln2.g" % i], w["l%d.ln2.b" % i], out=ws["h"])
-            ops.linear(ws["h"], w["l%d.fc1.w" % i], w["l%d.fc1.b" % i], act=ACT_GELU, out=ws["ffn"])
-            ops.gemm_raw(M, D, cfg.ffn, ws["ffn"], rowmap(M, 0, cfg.ffn), w["l%d.fc2.w" % i], cfg.ffn, x, xmap, OCC_F32, code,
+            ops.linear(ws["h"], w["l%d.fc1.w" % i], w["l%d.fc1.b" % i], act=ACT_GELU, out=ws["ffn"], ab_dtype=ab)
+            ops.gemm_raw(M, D, cfg.ffn, ws["ffn"], rowmap(M, 0, cfg.ffn), w["l%d.fc2.w" % i], cfg.ffn, x, xmap, OCC_F32, ab,
                          bias=w["l%d.fc2.b" % i], R=x, r_map=xmap, r_dtype=OCC_F32)
             if taps is not None:
                 taps["layer%d" % i] = x.view(B, T, D).clone()
@@ -262,7 +269,7 @@ class SSLModel(torch.nn.Module):
     _eval_at_init = True
 
     def __init__(self, device="cuda", cp_path=None, state_dict=None, cfg=None, dtype=torch.bfloat16, seed=0, finetune=False, synthetic=False,
-                 train_cfg=None):
+                 train_cfg=None, f32_gemm="exact"):
         super().__init__()
         self.device = device
         self.cfg = cfg or XlsrConfig.xlsr_300m()
@@ -288,7 +295,7 @@ class SSLModel(torch.nn.Module):
         elif finetune:                 # the reference's optimizer holds every SSL parameter (oc_training.py:324): end-to-end
             self.model = XlsrFullFineTuner(self._params, self.cfg, device=device)
         else:
-            self.model = XlsrFrontend(self._params, self.cfg, device=device, dtype=dtype)
+            self.model = XlsrFrontend(self._params, self.cfg, device=device, dtype=dtype, f32_gemm=f32_gemm)
         if self._eval_at_init:
             self.model.eval()                  # xlsr.py:34 (sslassist.SSLModel has no such call: quirk 10 of SURVEY.md section 8a)
         self.param_set = None

@@ -17,7 +17,7 @@ from . import ops
 from .data_utils_SSL import load_audio
 
 
-SSL_DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16}
+SSL_DTYPES = {"f32": torch.float32, "f32x3": torch.float32, "bf16": torch.bfloat16}
 
 
 class ASVDataset(Dataset):
@@ -254,11 +254,13 @@ def main(argv=None):
     parser.add_argument("--batch_size", type=int, default=1, help="1 = the reference's one-utterance loop; > 1 = batches of utterances of similar length, zero-padded "
                         "to the longest, with key masks in the front-end (each utterance's result equals its one-at-a-time result)")
     parser.add_argument("--num_workers", type=int, default=0)
-    parser.add_argument("--ssl_dtype", choices=["f32", "bf16"], default="f32",
+    parser.add_argument("--ssl_dtype", choices=["f32", "f32x3", "bf16"], default="f32",
                         help="arithmetic of the XLS-R front-end and the AASIST GEMMs: f32 (default) = exact-f32 MFMA, the path that meets the 1e-3 "
                              "parity bar against the reference's fp32 (embeddings within 2e-5 of the CPU oracle on the 24-layer model); bf16 = bf16 "
                              "MFMA with f32 accumulate, the training arithmetic: faster, but on the 24-layer model embeddings move by up to ~2.5 and "
-                             "distances by up to ~1 (DESIGN.md section 5, profiles/r03_scoring_parity_300m.json)")
+                             "distances by up to ~1 (DESIGN.md section 5, profiles/r03_scoring_parity_300m.json); f32x3 = f32 storage, every GEMM operand "
+                             "split into bf16 hi + lo and multiplied with three bf16 MFMAs (products exact to 2^-16): the f32 path's accuracy class at a "
+                             "multiple of its GEMM rate")
     args = parser.parse_args(argv)
     from .models.sslassist import AModel
     from . import parallel
@@ -271,7 +273,8 @@ def main(argv=None):
     # source of the XLS-R weights; a tensor that is missing or has the wrong shape is an error, never a silently random front-end.
     sd = torch.load(args.pretrained_sslaasist, map_location="cpu")
     ssl = {k[len("ssl_model.model."):]: v for k, v in sd.items() if k.startswith("ssl_model.model.")}
-    aasist = AModel(None, device, ssl_state_dict=ssl, ssl_dtype=SSL_DTYPES[args.ssl_dtype])      # back-end compute follows (f32 -> "f32")
+    aasist = AModel(None, device, ssl_state_dict=ssl, ssl_dtype=SSL_DTYPES[args.ssl_dtype],      # back-end compute follows (f32 -> "f32")
+                    ssl_f32_gemm="x3" if args.ssl_dtype == "f32x3" else "exact")
     aasist.load_state_dict(sd, strict=True)
     print("Pretrained weights loaded")
     kw = dict(batch_size=args.batch_size, rank=rank, world=world)

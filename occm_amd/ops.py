@@ -74,8 +74,9 @@ def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, 
     check(lib().occ_gemm(ctypes.byref(d), stream_ptr()), "occ_gemm")
 
 
-def linear(x, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, alpha=1.0):
-    """y = act(alpha * x @ w.T + bias) + residual for 2-D row-major x [M,K], w [N,K]."""
+def linear(x, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, alpha=1.0, ab_dtype=None):
+    """y = act(alpha * x @ w.T + bias) + residual for 2-D row-major x [M,K], w [N,K].  ab_dtype: the GEMM's arithmetic when it is not the
+    operands' storage type (OCC_F32X3 on f32 operands)."""
     _dev(x); _dev(w)
     M, K = x.shape
     N = w.shape[0]
@@ -83,7 +84,7 @@ def linear(x, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=Non
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=out_dtype or x.dtype)
     full = rowmap(M, 0, K)
-    gemm_raw(M, N, K, x, full, w, K, out, rowmap(M, 0, N), dtype_code(out), dtype_code(x), bias=bias, act=act, alpha=alpha,
+    gemm_raw(M, N, K, x, full, w, K, out, rowmap(M, 0, N), dtype_code(out), dtype_code(x) if ab_dtype is None else ab_dtype, bias=bias, act=act, alpha=alpha,
              R=residual, r_map=None if residual is None else rowmap(M, 0, N),
              r_dtype=OCC_F32 if residual is None else dtype_code(residual))
     return out

@@ -15,7 +15,7 @@ from occm_amd.oc_classifier import embed_dataset, n_frames
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=96)
-ap.add_argument("--dtypes", default="f32,bf16")
+ap.add_argument("--dtypes", default="f32,f32x3,bf16")
 ap.add_argument("--batches", default="1,8,16")
 ap.add_argument("--equal", action="store_true", help="also time the un-masked fallback (batches of equal frame count only)")
 args = ap.parse_args()
@@ -50,8 +50,8 @@ cfg = xlsr.XlsrConfig.xlsr_300m()
 flops = sum(fe_flops(L, cfg) for L in ds.lens)
 audio_s = sum(ds.lens) / 16000.0
 for dname in args.dtypes.split(","):
-    dt = {"f32": torch.float32, "bf16": torch.bfloat16}[dname]
-    model = AModel(None, "cuda", ssl_cfg=cfg, ssl_dtype=dt, synthetic_ssl=True)
+    dt = {"f32": torch.float32, "f32x3": torch.float32, "bf16": torch.bfloat16}[dname]
+    model = AModel(None, "cuda", ssl_cfg=cfg, ssl_dtype=dt, synthetic_ssl=True, ssl_f32_gemm="x3" if dname == "f32x3" else "exact")
     model.eval()
     base = None
     for bs in [int(v) for v in args.batches.split(",")]:
@@ -64,7 +64,7 @@ for dname in args.dtypes.split(","):
             dtm = time.perf_counter() - t0
             if base is None:
                 base = emb.clone()
-            peak = 157.3 if dname == "f32" else 2500.0
+            peak = 157.3 if dname == "f32" else (2500.0 / 3 if dname == "f32x3" else 2500.0)        # x3: three bf16 MFMAs per product
             print(json.dumps({"what": "scoring (embed_dataset)", "dtype": dname, "batch_size": bs, "masked_batches": bool(masked and bs > 1), "utterances": args.n,
                               "mean_seconds_per_utt": round(audio_s / args.n, 2), "utt_per_s": round(args.n / dtm, 2), "audio_s_per_s": round(audio_s / dtm, 1),
                               "frontend_tflops": round(flops / dtm / 1e12, 2), "peak_tflops": peak, "frac_of_peak": round(flops / dtm / 1e12 / peak, 4),

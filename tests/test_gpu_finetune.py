@@ -583,3 +583,37 @@ def test_transpose_bf16_batch_one_launch_many_jobs():
         ref = src[:, :cols].float().t().bfloat16()
         assert torch.equal(dst[:, :rows], ref)
         assert bool((dst[:, rows:] == 7.0).all())
+
+
+@pytest.mark.parametrize("B,L,dact_dt", [(3, 20003, torch.bfloat16), (2, 64000, torch.bfloat16), (1, 4000, torch.float32), (5, 330, torch.bfloat16)])
+def test_conv0_block_forward_and_backward_match_torch_autograd(B, L, dact_dt):
+    """Conv1d(1 -> 512, 10, 5) + LayerNorm(512) + GELU (fairseq's first conv block in layer_norm mode) on the matrix cores
+    (csrc/conv0_mfma.hip: split-operand bf16 MFMA): bf16 output against f64 torch, and d(loss)/d(w, bias, gamma, beta) from
+    occ_conv0_ln_gelu_bwd against f64 autograd of the same block fed with the same output gradient -- ragged tile ends (a last step of
+    fewer than 16 frames, a last tile of fewer than 8 steps), several utterances, bf16 and f32 gradients, accumulation onto what the
+    buffers hold."""
+    import torch.nn.functional as F
+    from occm_amd import ops
+    from occm_amd._lib import OCC_BF16, OCC_F32, check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(L)
+    T0 = (L - 10) // 5 + 1
+    wav = 0.1 * torch.randn(B, L, generator=g)
+    w = 0.3 * torch.randn(512, 10, generator=g); bias = 0.1 * torch.randn(512, generator=g)
+    gam = 1 + 0.1 * torch.randn(512, generator=g); bet = 0.1 * torch.randn(512, generator=g)
+    dact = torch.randn(B, T0, 512, generator=g).to(dact_dt)
+    pr = [t.double().requires_grad_(True) for t in (w, bias, gam, bet)]
+    pre = F.conv1d(wav.double()[:, None], pr[0][:, None], pr[1], stride=5).transpose(1, 2)            # [B, T0, 512]
+    y = F.gelu(F.layer_norm(pre, (512,), pr[2], pr[3], 1e-5))
+    y.backward(dact.double())
+    out = ops.conv0_ln_gelu(wav.cuda(), w.cuda(), bias.cuda(), gam.cuda(), bet.cuda(), 10, 5, out_dtype=torch.bfloat16)
+    err = (out.float().cpu().double() - y.detach()).abs()
+    assert float((err / (y.detach().abs() + 0.05)).max()) < 6e-3, float(err.max())                     # one bf16 rounding of the exact value
+    grads = [torch.full((512, 10), 0.25, device="cuda"), torch.full((512,), 0.25, device="cuda"), torch.full((512,), 0.25, device="cuda"), torch.full((512,), 0.25, device="cuda")]
+    dev = [t.cuda().contiguous() for t in (wav, w, bias, gam, bet, dact)]          # (kept alive: the call takes raw addresses)
+    check(lib().occ_conv0_ln_gelu_bwd(ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(dev[3]), ptr(dev[4]), ptr(dev[5]),
+                                      OCC_BF16 if dact_dt == torch.bfloat16 else OCC_F32, ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), B, L, T0, 512, 10, 5,
+                                      1e-5, stream_ptr()), "occ_conv0_ln_gelu_bwd")
+    torch.cuda.synchronize()
+    for name, got, ref in zip(("dw", "dbias", "dgamma", "dbeta"), grads, (p.grad for p in pr)):
+        d = (got.cpu().double() - 0.25 - ref).abs()
+        assert float(d.max()) <= 2e-4 * float(ref.abs().max()) + 1e-4, (name, float(d.max()), float(ref.abs().max()))

@@ -172,6 +172,7 @@ def test_finetune_300m_step_gradients_match_oracle_autograd_and_bs64_is_linear(o
         ld, dlog = ops.ce_loss(lg, lab.cuda(), scale=1.0, want_grad=True)
         dfe = be.backward(None, dlog, want_dfeats=True)
         fe.backward(dfe if inject is None else inject)
+        step.feats = f.detach().clone()
         return float(ld), fe.grad_dict(), dfe
     # (1) front-end backward in isolation
     _, gi, _ = step(wav, labels, inject=dfe_ref.cuda().contiguous())
@@ -191,6 +192,17 @@ def test_finetune_300m_step_gradients_match_oracle_autograd_and_bs64_is_linear(o
     l4, g4, dfe4 = step(wav, labels)
     assert abs(l4 - loss) < 5e-2 * max(1.0, abs(loss)), (l4, loss)       # bf16 features through a random-weight back-end: 2.3 % measured
     _grad_check(dfe4, dfe_ref, "dfeats", cos_min=0.8, rel_max=1.0)
+    # ... and that loose bound is a property of the FUNCTION, not of a kernel: the oracle's back-end evaluated on the DEVICE's own features
+    # (same input, same top-k candidates, same BatchNorm batch) gives the device's loss and feature gradient tightly.  So every link is
+    # tight on identical inputs -- front-end forward (3e-2 of bf16 round-off over 24 layers), back-end forward + backward (here), front-end
+    # backward ((1) above) -- and the 0.8 is what a random-weight AASIST with BatchNorm over four utterances makes of a 3e-2 input change.
+    fd = step.feats.cpu().float().requires_grad_(True)
+    _, out_d = aasist_ref.backend_forward(fd, pb, train=True)
+    loss_d = losses_ref.descriptiveness_loss(out_d, labels)
+    loss_d.backward()
+    assert abs(l4 - float(loss_d.detach())) < 2e-3 * max(1.0, abs(l4)), (l4, float(loss_d.detach()))
+    c_same, e_same = _grad_check(dfe4, fd.grad, "dfeats (oracle back-end on the device's features)", cos_min=0.99, rel_max=0.1)
+    print("back-end on identical features at full size: loss %.5f vs %.5f, feature-gradient cosine %.5f, max-relative error %.4f" % (l4, float(loss_d.detach()), c_same, e_same))
     for v in pr.values():
         v.grad = None
     feats.backward(dfe4.detach().cpu().float())
@@ -269,7 +281,7 @@ def test_config4_shard_xlsr1b_senet_bs32_bf16_and_fp8_training_steps():
         in bf16; under fp8 the per-tensor |max| -- hence every scale -- is the same for both batches as well: cosine >= 0.99);
         end to end (own back-end gradient; BatchNorm statistics of a replicated batch are unchanged) the random-weight SE-ResNet34 turns
         the round-off-level feature differences between the two batch sizes into a 10 % change of its feature gradient (measured cosine
-        0.88 - 0.91, the same effect as in the configs[2] test): bounded at cosine > 0.8 for bf16, the chain holds together (fp8: printed only);
+        0.88 - 0.91, the same effect as in the configs[2] test): bounded at cosine > 0.8 for bf16 and > 0.15 for fp8 (measured ~0.4);
     (3) fp8 against bf16 on the same batch and feature gradient: every checked XLS-R gradient tensor keeps cosine >= 0.9 (e4m3 x e4m3
         carries ~3.7 % error per linear layer, tests/test_gpu_fp8.py) and the loss moves by < 5 %;
     (4) the trainer object bench.py drives takes two full fp8 steps (RawBoost 5 on the GPU, backward, Adam over 964 M parameters): finite
@@ -331,8 +343,10 @@ def test_config4_shard_xlsr1b_senet_bs32_bf16_and_fp8_training_steps():
         e2e = {k: cos(g32[k], g4[k]) for k in lin}
         # (2) end to end.  Under fp8 the two batch sizes' features differ at the e4m3 quantisation-noise level (their conv stacks take
         # different bf16 kernels, and a last-bit input change re-rounds 3-bit mantissas through 48 layers); the back-end turns that into
-        # a feature gradient of cosine ~0.4 (measured): no bound is claimed there, the front-end itself is held by the fixed-gradient check.
-        assert mode == "fp8" or min(e2e.values()) > 0.8, (mode, e2e)
+        # a feature gradient of cosine ~0.4 (measured).  The front-end itself is held by the fixed-gradient check above; end to end the
+        # bound is that the two batch sizes' gradients stay clearly aligned (0.15: for tensors of 1e5..1e7 elements an unrelated or
+        # sign-flipped chain gives |cosine| < 1e-2 or a negative value).
+        assert min(e2e.values()) > (0.8 if mode == "bf16" else 0.15), (mode, e2e)
         out[mode] = (l32, gi32, min(lin.values()), min(e2e.values()))
     worst8 = {k: cos(out["fp8"][1][k], out["bf16"][1][k]) for k in lin}
     print("configs[4] shard: loss bf16 %.4f fp8 %.4f; bs-32 vs bs-4 worst cosine (fixed feature gradient / end to end) bf16 %.5f / %.3f, fp8 %.5f / %.3f; "
