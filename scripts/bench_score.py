@@ -56,7 +56,7 @@ for dname in args.dtypes.split(","):
     base = None
     for bs in [int(v) for v in args.batches.split(",")]:
         for masked in ([True, False] if (args.equal and bs > 1) else [True]):
-            embed_dataset(model, torch.utils.data.DataLoader(Trials(8, seed=1), batch_size=1), "cuda", bs, masked=masked)      # warm-up (workspaces, kernels)
+            embed_dataset(model, loader, "cuda", bs, masked=masked)      # warm-up pass over the same trials: a long evaluation runs with every workspace shape already allocated
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             emb, _ = embed_dataset(model, loader, "cuda", bs, masked=masked)
