@@ -397,6 +397,10 @@ int occ_attention(const void* qkv, void* out, int dtype, int64_t B, int64_t T, i
  * one-utterance loop, oc_classifier.py:182-186, 256-261): kv_len int32 [B] (device) = valid frames of each utterance; keys at or past
  * it are masked, so rows [0, kv_len[b]) equal the un-padded single-utterance result; rows past it are not meaningful.
  * f32-arithmetic kernels (storage f32 or bf16), any T.                                                                    */
+/* f32 -> three bf16 K-panels [rows, 3K] for an f32-grade product on the bf16 MFMA as ONE GEMM of depth 3K (no reference counterpart: the
+ * reference scores in fp32, oc_classifier.py:159-202; this is the arithmetic that keeps its accuracy class at the bf16 kernels' rate):
+ * mode 0 (activations) [hi | lo | hi], mode 1 (weights) [hi | hi | lo], hi = bf16(v), lo = bf16(v - hi).  x rows through x_map, K %% 8 == 0. */
+int occ_split3_bf16(const float* x, const occ_rowmap* x_map, void* out, int64_t rows, int64_t K, int mode, void* stream);
 int occ_attention_varlen(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd,
                          int64_t ld_qkv, int64_t ld_out, float scale, const int32_t* kv_len, void* stream);
 /* ---- backward of the transformer encoder (fine-tuning; autograd of fairseq's pre-LN TransformerSentenceEncoderLayer) ---- */

@@ -34,6 +34,7 @@ struct Args {
     const char* B; RowMapI bmap;       // X  [M, N2]
     float* C; long long ldc; float alpha;
     int t1, t2, S;                     // tiles along N1 / N2, pieces of the reduction
+    int piece_major;                   // block -> (piece, tile) order, see tn_map
     int nt;                            // K-tiles (64 rows) in all; piece s takes [s*nt/S, (s+1)*nt/S)
     int plain;                         // both row maps are m * row_stride: the K advance is a scalar add
     float* slabs;                      // [tile][piece][8 waves][32 accumulators][64 lanes] f32x4, pieces > 1 only
@@ -77,10 +78,8 @@ __device__ __forceinline__ int tn_vid() {
 }
 
 template <bool PLAIN>
-__device__ __forceinline__ void tn_p8_body(const Args& a, const int vid) {
+__device__ __forceinline__ void tn_p8_body(const Args& a, const int piece, const int tile) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 65536];
-    // block -> (tile, piece): the pieces of one tile are neighbours in the XCD-contiguous order (their slabs meet in one L2)
-    const int piece = vid % a.S, tile = vid / a.S;
     const int tx = tile % a.t1, ty = tile / a.t1;
     const long long n1_0 = (long long)tx * 256, n2_0 = (long long)ty * 256;
     const int kt0 = (int)((long long)piece * a.nt / a.S), kt1 = (int)((long long)(piece + 1) * a.nt / a.S);
@@ -249,8 +248,22 @@ __device__ __forceinline__ void tn_p8_body(const Args& a, const int vid) {
     }
 }
 
+// block -> (piece, tile).  Every workgroup of a launch is resident at once (tiles x pieces <= CUs), so what an XCD's L2 can share is decided by
+// which 32 workgroups land on it.  piece_major (round 4): an XCD takes ONE piece of the reduction (a contiguous range of operand rows) for a
+// run of consecutive tiles, so the row range of every operand panel those tiles touch is fetched once per XCD and reused by all of them --
+// the old order (a tile's pieces side by side) gave an XCD eight tiles x all pieces, i.e. eight full-length panels of dY that nothing shared
+// (measured 615 MB per paired launch against 170 / 290 MB algorithmic).
+__device__ __forceinline__ void tn_map(const int vid, const int tiles, const int S, const int piece_major, int& piece, int& tile) {
+    if (piece_major) { piece = vid / tiles; tile = vid - piece * tiles; }
+    else { piece = vid % S; tile = vid / S; }
+}
+
 template <bool PLAIN>
-__global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(const Args a) { tn_p8_body<PLAIN>(a, tn_vid()); }
+__global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(const Args a) {
+    int piece, tile;
+    tn_map(tn_vid(), a.t1 * a.t2, a.S, a.piece_major, piece, tile);
+    tn_p8_body<PLAIN>(a, piece, tile);
+}
 
 // Two products of one layer in one launch (out-proj with qkv, fc2 with fc1: same reduction length, different operands).  Each launch has
 // one workgroup per CU and leaves 64 MB of f32 slabs however few tiles it has, so two launches of 16 + 48 tiles cut their reductions 16
@@ -259,8 +272,17 @@ struct ArgsPair { Args v[2]; int wgs0; };
 template <bool PLAIN>
 __global__ __launch_bounds__(512, 2) void gemm_tn_p8_pair_kernel(const ArgsPair ap) {
     const int vid = tn_vid();
-    const int second = vid >= ap.wgs0 ? 1 : 0;          // wave-uniform: the argument block is read from the kernel-argument segment
-    tn_p8_body<PLAIN>(ap.v[second], vid - (second ? ap.wgs0 : 0));
+    const int tiles0 = ap.v[0].t1 * ap.v[0].t2;
+    if (ap.v[0].piece_major) {                          // (piece, then the tiles of both products in a row)
+        int piece, t;
+        tn_map(vid, tiles0 + ap.v[1].t1 * ap.v[1].t2, ap.v[0].S, 1, piece, t);
+        const int second = t >= tiles0 ? 1 : 0;         // wave-uniform: the argument block is read from the kernel-argument segment
+        tn_p8_body<PLAIN>(ap.v[second], piece, t - (second ? tiles0 : 0));
+        return;
+    }
+    const int second = vid >= ap.wgs0 ? 1 : 0;
+    const int v2 = vid - (second ? ap.wgs0 : 0);
+    tn_p8_body<PLAIN>(ap.v[second], v2 % ap.v[second].S, v2 / ap.v[second].S);
 }
 
 // C += alpha * sum over pieces of the slabs (reduce_kernel mode): thread = one f32x4 of one (tile, wave, accumulator, lane) slot,
@@ -327,6 +349,8 @@ int occ_tn_p8_pair_try(long long M, const long long* N1, const long long* N2, co
         a.t1 = (int)(N1[p] / 256); a.t2 = (int)(N2[p] / 256);
         a.nt = (int)(M / 64);
         a.plain = 1; a.store = store[p];
+        static const int pm_env = getenv("OCC_TN_PIECE_MAJOR") ? atoi(getenv("OCC_TN_PIECE_MAJOR")) : 1;
+        a.piece_major = pm_env;
         tiles[p] = (long long)a.t1 * a.t2;
     }
     static int cus = 0;
@@ -357,6 +381,8 @@ int occ_tn_p8_try(long long M, long long N1, long long N2, const void* A, const 
     a.N1 = N1; a.N2 = N2; a.A = (const char*)A; a.amap = amap; a.B = (const char*)B; a.bmap = bmap; a.C = C; a.ldc = ldc; a.alpha = alpha;
     a.t1 = (int)(N1 / 256); a.t2 = (int)(N2 / 256);
     a.nt = (int)(M / 64); a.store = store;
+    static const int pm_env = getenv("OCC_TN_PIECE_MAJOR") ? atoi(getenv("OCC_TN_PIECE_MAJOR")) : 1;
+    a.piece_major = pm_env;
     a.plain = amap.rpl == 0 && bmap.rpl == 0 && amap.rpb >= M && bmap.rpb >= M;
     static int cus = 0;
     if (!cus) { int dev = 0, v = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }

@@ -134,6 +134,12 @@ class XlsrFrontend(torch.nn.Module):
             w["l%d.fc2.w" % i] = cd(p[pre + ".fc2.weight"]); w["l%d.fc2.b" % i] = f32(p[pre + ".fc2.bias"])
             w["l%d.ln2.g" % i] = f32(p[pre + ".final_layer_norm.weight"]); w["l%d.ln2.b" % i] = f32(p[pre + ".final_layer_norm.bias"])
         w["enc_ln.g"] = f32(p["encoder.layer_norm.weight"]); w["enc_ln.b"] = f32(p["encoder.layer_norm.bias"])
+        if dt == torch.float32 and self.f32_gemm == "x3":
+            # the transformer linears (82 % of the FLOPs) as ONE bf16 GEMM of depth 3K on the LDS-DMA kernels: weights [wh | wh | wl] here,
+            # activations [xh | xl | xh] in front of every GEMM (forward)
+            for i in range(self.cfg.layers):
+                for n in ("qkv", "o", "fc1", "fc2"):
+                    w["l%d.%s.w3" % (i, n)] = ops.split3_bf16(w["l%d.%s.w" % (i, n)], mode=1)
         self.w = w
 
     # -- activation workspace, cached per (B, L) -------------------------------------------------
@@ -159,6 +165,8 @@ class XlsrFrontend(torch.nn.Module):
             ws["qkv"] = torch.empty(M, 3 * cfg.dim, device=dev, dtype=dt)
             ws["att"] = torch.empty(M, cfg.dim, device=dev, dtype=dt)
             ws["ffn"] = torch.empty(M, cfg.ffn, device=dev, dtype=dt)
+            if dt == torch.float32 and self.f32_gemm == "x3":
+                ws["a3"] = torch.empty(M, 3 * max(cfg.dim, cfg.ffn), device=dev, dtype=torch.bfloat16)       # [hi | lo | hi] copy of a GEMM's input
             self._ws[key] = ws
             while len(self._ws) > WS_CACHE:            # variable-length scoring meets thousands of (B, L): keep the most recent shapes only
                 self._ws.pop(next(iter(self._ws)))
@@ -236,6 +244,11 @@ class XlsrFrontend(torch.nn.Module):
         xmap = rowmap(M, 0, D)
         for i in range(cfg.layers):
             ops.layernorm(x, w["l%d.ln1.g" % i], w["l%d.ln1.b" % i], out=ws["h"])
+            if "a3" in ws:
+                self._layer_x3(i, ws, x, xmap, M, D, B, T, hd, kv_len)
+                if taps is not None:
+                    taps["layer%d" % i] = x.view(B, T, D).clone()
+                continue
             ops.linear(ws["h"], w["l%d.qkv.w" % i], w["l%d.qkv.b" % i], out=ws["qkv"], ab_dtype=ab)
             if kv_len is not None:
                 ops.attention_varlen(ws["qkv"], B, T, cfg.heads, hd, hd ** -0.5, kv_len, out=ws["att"])
@@ -253,6 +266,27 @@ class XlsrFrontend(torch.nn.Module):
             dst = torch.empty(B, T, D, device=self.device, dtype=out_dtype or dt)
         ops.layernorm(x, w["enc_ln.g"], w["enc_ln.b"], out=dst.view(M, D))
         return dst
+
+
+    def _x3(self, ws, a, M, K, wname, N, C, c_map, **kw):
+        """C = act(a . W^T + bias) (+ R) with f32-grade products at the bf16 kernels' rate: a (f32 [M, K]) -> [ah | al | ah], W stored as
+        [wh | wh | wl]: ONE bf16 GEMM of depth 3K = ah.wh + al.wh + ah.wl, f32 accumulate, f32 result."""
+        a3 = ws["a3"].view(-1)[: M * 3 * K].view(M, 3 * K)
+        ops.split3_bf16(a, out=a3, mode=0, rows=M, K=K)
+        ops.gemm_raw(M, N, 3 * K, a3, rowmap(M, 0, 3 * K), self.w[wname], 3 * K, C, c_map, OCC_F32, OCC_BF16_CODE, **kw)
+
+    def _layer_x3(self, i, ws, x, xmap, M, D, B, T, hd, kv_len):
+        """One pre-LN transformer layer of the f32 path with split-operand linears (ws["h"] already holds LN1(x))."""
+        cfg, w = self.cfg, self.w
+        self._x3(ws, ws["h"], M, D, "l%d.qkv.w3" % i, 3 * D, ws["qkv"], rowmap(M, 0, 3 * D), bias=w["l%d.qkv.b" % i])
+        if kv_len is not None:
+            ops.attention_varlen(ws["qkv"], B, T, cfg.heads, hd, hd ** -0.5, kv_len, out=ws["att"])
+        else:
+            ops.attention(ws["qkv"], B, T, cfg.heads, hd, hd ** -0.5, out=ws["att"])
+        self._x3(ws, ws["att"], M, D, "l%d.o.w3" % i, D, x, xmap, bias=w["l%d.o.b" % i], R=x, r_map=xmap, r_dtype=OCC_F32)
+        ops.layernorm(x, w["l%d.ln2.g" % i], w["l%d.ln2.b" % i], out=ws["h"])
+        self._x3(ws, ws["h"], M, D, "l%d.fc1.w3" % i, cfg.ffn, ws["ffn"], rowmap(M, 0, cfg.ffn), bias=w["l%d.fc1.b" % i], act=ACT_GELU)
+        self._x3(ws, ws["ffn"], M, cfg.ffn, "l%d.fc2.w3" % i, D, x, xmap, bias=w["l%d.fc2.b" % i], R=x, r_map=xmap, r_dtype=OCC_F32)
 
 
 class SSLModel(torch.nn.Module):

@@ -124,6 +124,18 @@ def attention(qkv, B, T, H, hd, scale, out=None, lse=None):
     return out
 
 
+def split3_bf16(x, out=None, mode=0, x_map=None, rows=None, K=None):
+    """f32 [rows, K] -> bf16 [rows, 3K]: [hi | lo | hi] (mode 0, activations) or [hi | hi | lo] (mode 1, weights); the two then multiply
+    as ONE bf16 GEMM of depth 3K that yields xh.wh + xl.wh + xh.wl (occ_split3_bf16)."""
+    if rows is None:
+        rows, K = x.shape
+    if out is None:
+        out = torch.empty(rows, 3 * K, device=x.device, dtype=torch.bfloat16)
+    m = x_map if x_map is not None else rowmap(rows, 0, K)
+    check(lib().occ_split3_bf16(x if isinstance(x, int) else ptr(x), ctypes.byref(m), ptr(out), int(rows), int(K), int(mode), stream_ptr()), "occ_split3_bf16")
+    return out
+
+
 def attention_varlen(qkv, B, T, H, hd, scale, kv_len, out=None):
     """Attention over a zero-padded batch: kv_len int32 [B] (device) = valid frames per utterance; keys at or past it are masked, so the
     first kv_len[b] rows of utterance b equal its un-padded single-utterance result (f32 arithmetic, storage f32 or bf16)."""

@@ -18,4 +18,18 @@ for M, N, K in ((199, 1024, 1024), (3184, 1024, 1024), (3184, 4096, 1024), (3184
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
         line += " | %s %7.1f us %6.1f TF" % (name, us, 2 * M * N * K / us / 1e6)
+    # the fast form: [xh | xl | xh] . [wh | wh | wl]^T as ONE bf16 GEMM of depth 3K on the LDS-DMA kernels (weights split once, the activation
+    # split timed with the product)
+    w3 = ops.split3_bf16(w, mode=1); a3 = torch.empty(M, 3 * K, device="cuda", dtype=torch.bfloat16)
+    def run3():
+        ops.split3_bf16(x, out=a3, mode=0)
+        ops.gemm_raw(M, N, 3 * K, a3, ops.rowmap(M, 0, 3 * K), w3, 3 * K, out, ops.rowmap(M, 0, N), ops.OCC_F32, ops.OCC_BF16, bias=b)
+    run3(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        run3()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    line += " | split + 3K bf16 GEMM %7.1f us %6.1f TF (of the f32 product)" % (us, 2 * M * N * K / us / 1e6)
     print(line, flush=True)

@@ -24,14 +24,11 @@ for k in sorted(set(ft) | set(wt)):
     f = ft[k] / max(fc[k], 1); w = wt[k] / max(wc[k], 1)
     out["kernels"][k] = {"FETCH_SIZE_KiB_per_launch": round(f, 1), "WRITE_SIZE_KiB_per_launch": round(w, 1),
                          "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024), "launches": max(fc[k], wc[k])}
-import hashlib, os
+import os
 _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_h = hashlib.sha256()
-for _n in ("gemm.hip", "gemm_common.h", "gemm_tn.hip", "gemm_p8.hip", "gemm_tn_p8.hip"):       # the same list as bench.py GEMM_SOURCES: the profile is tied to these sources
-    _p = os.path.join(_root, "occm_amd", "csrc", _n)
-    if os.path.exists(_p):
-        _h.update(open(_p, "rb").read())
-out["gemm_src_sha16"] = _h.hexdigest()[:16]
+sys.path.insert(0, _root)
+import bench                                    # ONE list of GEMM sources (bench.GEMM_SOURCES): the profile is tied to exactly the files bench.py hashes
+out["gemm_src_sha16"] = bench.gemm_source_sha()
 # the workload the counters were taken on (bench.py's config.workload string + dtype): bench.py reports `traffic` only for that workload
 if len(sys.argv) > 4:
     out["workload"] = sys.argv[4]

@@ -409,6 +409,32 @@ def test_f32x3_split_operand_gemm_is_f32_grade(M, N, K):
     assert float((out.cpu().double() - ref2).abs().max()) < 3e-5 * float(ref2.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(199, 1024, 1024), (3184, 4096, 1024), (3184, 1024, 4096), (12736, 3072, 1024)])
+def test_split3_panels_give_an_f32_grade_product_as_one_bf16_gemm(M, N, K):
+    """occ_split3_bf16: activations [xh | xl | xh], weights [wh | wh | wl]; ONE bf16 GEMM of depth 3K on the LDS-DMA kernels then equals
+    xh.wh + xl.wh + xh.wl.  Panels bit-exact against torch; the product within 2e-5 of the largest f64 output (the exact-f32 kernel's
+    class, ~100x below a bf16-operand product), with bias, GELU and an f32 residual that aliases the output (the out-proj / fc2 form)."""
+    from occm_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g); r = torch.randn(M, N, generator=g)
+    a3, w3 = ops.split3_bf16(x.cuda(), mode=0), ops.split3_bf16(w.cuda(), mode=1)
+    xh = x.bfloat16(); xl = (x - xh.float()).bfloat16()
+    wh = w.bfloat16(); wl = (w - wh.float()).bfloat16()
+    assert torch.equal(a3.cpu(), torch.cat([xh, xl, xh], 1)) and torch.equal(w3.cpu(), torch.cat([wh, wh, wl], 1))
+    ref = x.double() @ w.double().T + b.double()
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm_raw(M, N, 3 * K, a3, ops.rowmap(M, 0, 3 * K), w3, 3 * K, out, ops.rowmap(M, 0, N), ops.OCC_F32, ops.OCC_BF16, bias=b.cuda())
+    assert float((out.cpu().double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    c = r.cuda().clone()
+    ops.gemm_raw(M, N, 3 * K, a3, ops.rowmap(M, 0, 3 * K), w3, 3 * K, c, ops.rowmap(M, 0, N), ops.OCC_F32, ops.OCC_BF16, bias=b.cuda(), R=c, r_map=ops.rowmap(M, 0, N),
+                 r_dtype=ops.OCC_F32)
+    assert float((c.cpu().double() - (ref + r.double())).abs().max()) < 2e-5 * float(ref.abs().max())
+    o2 = torch.empty(M, N, device="cuda")
+    ops.gemm_raw(M, N, 3 * K, a3, ops.rowmap(M, 0, 3 * K), w3, 3 * K, o2, ops.rowmap(M, 0, N), ops.OCC_F32, ops.OCC_BF16, bias=b.cuda(), act=ops.ACT_GELU)
+    assert float((o2.cpu().double() - torch.nn.functional.gelu(ref)).abs().max()) < 3e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("case,gemm", [("a", "exact"), ("b", "exact"), ("b", "x3")])
 def test_xlsr_f32_path_matches_huggingface_proxy_fixtures(case, gemm):
     """HIP f32-MFMA front-end vs outputs of HuggingFace ``Wav2Vec2Model`` at the XLS-R-300M geometry (tests/golden/xlsr_hf.npz, written in
