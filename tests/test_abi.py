@@ -47,7 +47,7 @@ _NO_SCRATCH = ["gemm_bf16_dma_kernelILi128ELb0ELi128", "gemm_bf16_dma_kernelILi1
                "layernorm_bwd16_kernelItfLi3ELb0ELi8ELb1", "layernorm_bwd16_kernelIttLi1ELb1", "layernorm_kernelIftLi2ELb1", "attention_mfma_long_kernel",
                # round 4: the separate-pass LayerNorm backward at C = 1024 (the route residual dropout / layerdrop take: 12 waves, the 16-wave
                # form spilled) and the four-wave GEMM
-               "Li2ELb0ELi12ELb0EEEv", "gemm_q4_kernel"]
+               "Li2ELb0ELi12ELb0EEEv", "gemm_q4_kernel", "conv0_mfma_kernel", "conv0_bwd_mfma_kernel", "gemm_kernelILi4ELi128"]
 
 
 def test_hot_kernels_do_not_spill():

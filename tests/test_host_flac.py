@@ -1,6 +1,6 @@
 """Host FLAC decoder of the input pipeline (occ_flac_info / occ_flac_decode through occm_amd.data_utils_SSL) against streams written by the
 test-only encoder tests/flac_writer.py: bit-exact PCM for every subframe type and stereo mode, CRC / MD5 failures are reported.
-No GPU needed (the decoder is host code inside libocc_hip.so).  Not validated against libFLAC-encoded files: none exist in this image."""
+No GPU needed (the decoder is host code inside libocc_hip.so).  libFLAC-written known answers: the RFC 9639 Appendix D example streams (last test)."""
 import os
 
 import numpy as np
