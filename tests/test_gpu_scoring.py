@@ -427,3 +427,29 @@ def test_masked_batches_of_unequal_utterances_equal_one_at_a_time(tmp_path, monk
         eu, _ = model.backend.forward(feats, train=False)
     torch.testing.assert_close(em[0], e1[0], rtol=2e-4, atol=2e-4)
     assert float((eu[0] - e1[0]).abs().max()) > 1e-2
+
+
+def test_two_model_scoring_form_in_masked_batches_equals_one_at_a_time():
+    """The (extractor, encoder) pair of oc_classifier.py:139-144 -- SSLModel features -> unsqueeze(1) -> se_resnet34 -- through
+    ExtractorEncoder with lengths: the front-end runs the zero-padded batch with key masks, the encoder once per distinct frame count."""
+    from oracle import xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.models import xlsr
+    from occm_amd.models.senet import se_resnet34
+    from occm_amd.oc_classifier import ExtractorEncoder
+    kw = dict(dim=1024, ffn=512, heads=16, layers=1)
+    ssl = xlsr.SSLModel("cuda", state_dict=fill_like(xlsr_ref.param_shapes(xlsr_ref.XlsrConfig(**kw)), seed=3), cfg=xlsr.XlsrConfig(**kw), dtype=torch.float32)
+    enc = se_resnet34(compute="f32")
+    pair = ExtractorEncoder(ssl, enc).eval()
+    lens = [24000, 17777, 24000, 30001]
+    g = torch.Generator().manual_seed(5)
+    wavs = [0.1 * torch.randn(L, generator=g) for L in lens]
+    x = torch.zeros(len(lens), max(lens))
+    for i, w in enumerate(wavs):
+        x[i, : w.numel()] = w
+    with torch.no_grad():
+        com, des = pair(x.cuda(), lengths=lens)
+        for i, w in enumerate(wavs):
+            c1, d1 = pair(w[None].cuda())
+            torch.testing.assert_close(com[i], c1[0], rtol=2e-4, atol=2e-4)
+            torch.testing.assert_close(des[i], d1[0], rtol=2e-4, atol=2e-4)
