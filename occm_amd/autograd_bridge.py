@@ -59,11 +59,11 @@ class ParamSet:
     def before_backward(self):
         """Decide how this backward's gradients meet what ``param.grad`` holds.  Returns a token for ``after_backward``."""
         eng = self.engine
-        n_none = sum(1 for p in self.params if p.grad is None)
-        if n_none == len(self.params):        # after optimizer.zero_grad(): start from zero
+        live = [(p, g) for p, g in zip(self.params, self.gviews) if p.requires_grad]      # frozen parameters never receive a .grad (as in torch)
+        if all(p.grad is None for p, _ in live):          # after optimizer.zero_grad(): start from zero
             eng.zero_grad()
             return ("fresh", None)
-        if all(self._aliases(p, g) for p, g in zip(self.params, self.gviews)):
+        if all(self._aliases(p, g) for p, g in live):
             if hasattr(eng, "grads_cleared"):
                 eng.grads_cleared = False     # the buffer holds gradients the engine did not see being cleared: accumulate, never store
             return ("accumulate", None)
@@ -77,10 +77,13 @@ class ParamSet:
             return
         if mode == "fresh":
             for p, g in zip(self.params, self.gviews):
-                p.grad = g
+                if p.requires_grad:
+                    p.grad = g
             return
         sv = self.engine.ref_views(saved)
         for name, p, g in zip(self.names, self.params, self.gviews):
+            if not p.requires_grad:
+                continue
             if p.grad is None:
                 p.grad = g
             elif self._aliases(p, g):

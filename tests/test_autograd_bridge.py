@@ -123,6 +123,9 @@ def test_no_grad_eval_and_the_one_tape_rule():
     with pytest.raises(RuntimeError, match="tape"):
         y1.sum().backward()
     y2.sum().backward()
+    m.lin.bias.requires_grad_(False); m.lin.bias.grad = None; m.lin.weight.grad = None
+    m(x)[0].sum().backward()
+    assert m.lin.bias.grad is None and m.lin.weight.grad is not None          # a frozen parameter gets no .grad, as in torch
     for p in m.parameters():
         p.requires_grad_(False)
     assert not m(x)[0].requires_grad                                          # nothing to differentiate: plain call
