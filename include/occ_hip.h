@@ -169,6 +169,7 @@ typedef struct occ_gemm_desc {
      * c_colsum_ws: caller-owned f32 scratch, >= 2 * ceil(M / 224) * N floats (per-tile partial sums, added in a fixed order by a
      * second small launch).  Same launch restrictions as c_f8.                                                              */
     float* c_colsum; float* c_colsum_ws; int64_t c_colsum_ws_floats;
+    int c_colsum_defer;                        /* 1: partial sums only, no finalize launch: see occ_finalize_batch (the caller keeps c_colsum_ws zero-initialised: a launch writes its 2 * ceil(M / tile rows) rows only) */
 } occ_gemm_desc;
 /* C = act(alpha * A.W^T + bias) + R.  Replaces every nn.Linear / Conv1d of the path
  * (fairseq wav2vec2 layers reached from sslassist.py:48; AModel.LL sslassist.py:509).             */
@@ -457,7 +458,20 @@ int occ_layernorm_fp8(const float* x, void* y_bf16, void* y_f8, const float* f8_
  * -- the operand and the next-step statistics of the fp8 input-gradient GEMM.  rows >= 2048, C <= 1536, scratch >= 768*C floats.    */
 int occ_layernorm_bwd_fused(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16,
                             float* dgamma, float* dbeta, float* dbias, void* dx_f8, const float* f8_scale, float* f8_amax, int64_t rows,
-                            int64_t C, float eps, float* scratch, int64_t scratch_floats, void* stream);
+                            int64_t C, float eps, float* scratch, int64_t scratch_floats, int defer, void* stream);
+/* defer (here, in occ_gemm_desc.c_colsum_defer and in occ_attention_bwd_bias): 1 = leave the per-workgroup partial sums in the scratch buffer
+ * (which must then be this call site's own until occ_finalize_batch has run) and skip the finalize launch; the caller adds every site's sums
+ * with ONE occ_finalize_batch launch after the backward pass.  Job layouts:
+ *   kind 0 (LayerNorm / column sums): partials [n0 rows][n1], out[i] += sum of the rows; i < n2 -> out0, < 2 n2 -> out1, else out2 (may be NULL).
+ *           LayerNorm: n0 = min(256, ceil(rows / 48)), n1 = 3 C, n2 = C, outs = dgamma, dbeta, dbias.  GEMM column sums: n0 = 2 ceil(M / tile rows)
+ *           (224 or 256, the dispatcher's choice: give n0 = 2 * ceil(M / 224) and keep the buffer zero-initialised), n1 = n2 = N, out0 = c_colsum.
+ *   kind 1 (attention q|k|v bias, one key block): partials [n0 = B][n1 = H][3][n2 = hd], out0 = dbias [3 * H * hd].
+ * n_blocks: kind 0 ceil(n1 / 64), kind 1 3 * n1; first_block = running sum, ascending.                                                */
+typedef struct occ_finalize_job {
+    const float* partials; float* out0; float* out1; float* out2;
+    int32_t kind, n0, n1, n2, first_block, n_blocks;
+} occ_finalize_job;
+int occ_finalize_batch(const occ_finalize_job* jobs_dev, int64_t n_jobs, int64_t total_blocks, void* stream);
 /* The keep-mask of occ_dropout_ex(generate = 1) on its own: mask[i] = 1 with probability 1 - p, Philox4x32-10 counter (i / 4, stream_id),
  * key seed -- the same bytes occ_dropout_ex writes for the same (n, p, seed, stream_id).                                          */
 int occ_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
@@ -475,7 +489,7 @@ int occ_attention_bwd_dropout(const void* qkv, const void* o, const void* dout, 
  * writes -- the separate pass over dqkv folded into the kernel that produces it.  bias_ws: f32 scratch >= B*H*3*hd floats.       */
 int occ_attention_bwd_bias(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H,
                            int64_t hd, int64_t ld_qkv, int64_t ld_o, float scale, float* dbias, float* bias_ws, int64_t bias_ws_floats,
-                           void* stream);
+                           int defer, void* stream);
 /* dq|dk|dv (bf16 [B*T, 3D], same layout as qkv) of softmax(scale q.k^T) v given o (forward output), dout and the forward's lse.
  * head_dim 64 or 80, any T.  T > 256 needs dq_accum: caller-owned f32 scratch [B*T, H*hd] (16-byte aligned) in which the key blocks
  * of a head meet; it may be NULL for T <= 256.                                                                   */

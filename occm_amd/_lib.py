@@ -35,7 +35,13 @@ class GemmDesc(ctypes.Structure):
                 ("w_group_stride", ctypes.c_int64), ("c_group_stride", ctypes.c_int64), ("aux", ctypes.c_void_p),
                 ("a_dequant", ctypes.c_void_p), ("w_dequant", ctypes.c_void_p),
                 ("c_f8", ctypes.c_void_p), ("c_f8_scale", ctypes.c_void_p), ("c_f8_amax", ctypes.c_void_p), ("c_f8_fmt", ctypes.c_int),
-                ("c_colsum", ctypes.c_void_p), ("c_colsum_ws", ctypes.c_void_p), ("c_colsum_ws_floats", ctypes.c_int64)]
+                ("c_colsum", ctypes.c_void_p), ("c_colsum_ws", ctypes.c_void_p), ("c_colsum_ws_floats", ctypes.c_int64), ("c_colsum_defer", ctypes.c_int)]
+
+
+class FinalizeJob(ctypes.Structure):
+    _fields_ = [("partials", ctypes.c_void_p), ("out0", ctypes.c_void_p), ("out1", ctypes.c_void_p), ("out2", ctypes.c_void_p),
+                ("kind", ctypes.c_int32), ("n0", ctypes.c_int32), ("n1", ctypes.c_int32), ("n2", ctypes.c_int32), ("first_block", ctypes.c_int32),
+                ("n_blocks", ctypes.c_int32)]
 
 
 class GemmTnDesc(ctypes.Structure):

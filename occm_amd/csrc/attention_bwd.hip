@@ -435,7 +435,7 @@ __global__ void attention_dq_finish_kernel(const float* __restrict__ acc, unsign
 template <int HD, bool DROP = false, bool BIAS = false>
 int launch_attention_bwd2(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* dq_accum, int64_t B, int64_t T, int64_t H,
                           int64_t ld_qkv, int64_t ld_o, float scale, hipStream_t s, const unsigned char* keep = nullptr, float p = 0.f, float* dbias = nullptr,
-                          float* bias_ws = nullptr) {
+                          float* bias_ws = nullptr, int defer = 0) {
     using C = AbCfg<HD>;
     const size_t shm = (size_t)AB_KEYS * C::ROWB + 4 * 32 * C::ROWB + 2 * AB_DS_BYTES + 128 * 4;
     hipError_t e = hipFuncSetAttribute((const void*)attention_bwd2_kernel<HD, DROP, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -445,7 +445,7 @@ int launch_attention_bwd2(const void* qkv, const void* o, const void* dout, cons
     hipLaunchKernelGGL((attention_bwd2_kernel<HD, DROP, BIAS>), dim3((unsigned)(B * H), (unsigned)nkb), dim3(512), shm, s, (const unsigned short*)qkv, (const unsigned short*)o,
                        (const unsigned short*)dout, lse, (unsigned short*)dqkv, dq_accum, (int)T, (int)H, (long long)ld_qkv, (long long)ld_o, scale, keep,
                        (int)((T + 3) / 4 * 4), 1.0f / (1.0f - p), dbias ? bias_ws : nullptr);
-    if (dbias)
+    if (dbias && !defer)                              // (defer: the records stay in bias_ws for occ_finalize_batch)
         hipLaunchKernelGGL(attention_bias_finalize_kernel, dim3((unsigned)(3 * H)), dim3(256), 0, s, (const float*)bias_ws, dbias, (int)B, (int)H, HD, (int)nkb);
     if (nkb > 1) {
         long long blocks = occ_cdiv(B * T * (H * HD / 4), 256);
@@ -458,13 +458,13 @@ int launch_attention_bwd2(const void* qkv, const void* o, const void* dout, cons
 }  // namespace
 
 extern "C" int occ_attention_bwd_bias(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T, int64_t H, int64_t hd,
-                                      int64_t ld_qkv, int64_t ld_o, float scale, float* dbias, float* bias_ws, int64_t bias_ws_floats, void* stream) {
+                                      int64_t ld_qkv, int64_t ld_o, float scale, float* dbias, float* bias_ws, int64_t bias_ws_floats, int defer, void* stream) {
     OCC_CHECK_ARG(qkv && o && dout && lse && dqkv && dbias && bias_ws, "occ_attention_bwd_bias: null pointer");
     OCC_CHECK_ARG((hd == 64 || hd == 80) && T >= 1 && T <= AB_KEYS && B >= 1 && H >= 1 && B * H < (1ll << 31), "occ_attention_bwd_bias: head_dim 64 or 80, T <= %d (one key block)", AB_KEYS);
     OCC_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_qkv >= 3 * H * hd && ld_o >= H * hd && bias_ws_floats >= B * H * 3 * hd, "occ_attention_bwd_bias: leading dimensions / scratch");
     int rc;
-    if (hd == 64) rc = launch_attention_bwd2<64, false, true>(qkv, o, dout, lse, dqkv, nullptr, B, T, H, ld_qkv, ld_o, scale, (hipStream_t)stream, nullptr, 0.f, dbias, bias_ws);
-    else rc = launch_attention_bwd2<80, false, true>(qkv, o, dout, lse, dqkv, nullptr, B, T, H, ld_qkv, ld_o, scale, (hipStream_t)stream, nullptr, 0.f, dbias, bias_ws);
+    if (hd == 64) rc = launch_attention_bwd2<64, false, true>(qkv, o, dout, lse, dqkv, nullptr, B, T, H, ld_qkv, ld_o, scale, (hipStream_t)stream, nullptr, 0.f, dbias, bias_ws, defer);
+    else rc = launch_attention_bwd2<80, false, true>(qkv, o, dout, lse, dqkv, nullptr, B, T, H, ld_qkv, ld_o, scale, (hipStream_t)stream, nullptr, 0.f, dbias, bias_ws, defer);
     if (rc != OCC_OK) return rc;
     OCC_LAUNCH_CHECK("occ_attention_bwd_bias");
     return OCC_OK;

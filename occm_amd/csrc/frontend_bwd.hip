@@ -815,15 +815,20 @@ int occ_layernorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
                     nullptr, nullptr, nullptr, nullptr);
 }
 
+static thread_local int g_lnb_defer = 0;        // occ_layernorm_bwd_fused(defer = 1): the partial sums stay in the caller's scratch (occ_finalize_batch adds them)
+
 int occ_layernorm_bwd_fused(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
                             float* dbeta, float* dbias, void* dx_f8, const float* f8_scale, float* f8_amax, int64_t rows, int64_t C, float eps,
-                            float* scratch, int64_t scratch_floats, void* stream) {
+                            float* scratch, int64_t scratch_floats, int defer, void* stream) {
+    g_lnb_defer = defer;
     OCC_CHECK_ARG(dbias || dx_f8, "occ_layernorm_bwd_fused: nothing to fuse (use occ_layernorm_bwd)");
     OCC_CHECK_ARG(!dx_f8 || (dx_bf16 && f8_scale), "occ_layernorm_bwd_fused: the fp8 copy is made of the bf16 output and needs its scale");
     OCC_CHECK_ARG(rows >= 2048 && C <= 1536 && scratch && scratch_floats >= 256 * 3 * C && ((uintptr_t)scratch & 15) == 0,
                   "occ_layernorm_bwd_fused: needs rows >= 2048, C <= 1536 and 768*C floats of 16-byte aligned scratch");
-    return lnb_impl(dy, dy_dtype, x, OCC_F32, gamma, nullptr, dres, dx, dx_bf16, nullptr, dgamma, dbeta, rows, C, eps, 0, scratch, scratch_floats, stream,
-                    dbias, dx_f8, f8_scale, f8_amax);
+    const int rc = lnb_impl(dy, dy_dtype, x, OCC_F32, gamma, nullptr, dres, dx, dx_bf16, nullptr, dgamma, dbeta, rows, C, eps, 0, scratch, scratch_floats, stream,
+                            dbias, dx_f8, f8_scale, f8_amax);
+    g_lnb_defer = 0;
+    return rc;
 }
 
 static int lnb_impl(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta, const float* dres, float* dx,
@@ -854,7 +859,8 @@ static int lnb_impl(const void* dy, int dy_dtype, const void* x, int x_dtype, co
         if (dy_dtype == OCC_F32) { if (nitx == 1) OCC_LNBX(float, 1, 12); else if (nitx == 2) OCC_LNBX(float, 2, 12); else OCC_LNBX(float, 3, 8); }
         else { if (nitx == 1) OCC_LNBX(unsigned short, 1, 12); else if (nitx == 2) OCC_LNBX(unsigned short, 2, 12); else OCC_LNBX(unsigned short, 3, 8); }
 #undef OCC_LNBX
-        hipLaunchKernelGGL(layernorm_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(3 * C, 64)), dim3(256), 0, s, scratch, (int)bl, (int)C, dgamma, dbeta, dbias, 3);
+        if (!g_lnb_defer)
+            hipLaunchKernelGGL(layernorm_bwd_finalize_kernel, dim3((unsigned)occ_cdiv(3 * C, 64)), dim3(256), 0, s, scratch, (int)bl, (int)C, dgamma, dbeta, dbias, 3);
         OCC_LAUNCH_CHECK("occ_layernorm_bwd_fused");
         return OCC_OK;
     }

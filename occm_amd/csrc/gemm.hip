@@ -699,7 +699,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         OCC_CHECK_ARG(p8_fits, "occ_gemm: fp8 operands too large for 32-bit DMA offsets");
         g_last_kernel = OCC_GEMM_KERNEL_P8_FP8;
         gemm_p8_launch(a, s, d->ab_dtype == OCC_FP8_E4M3 ? 1 : 2);
-        if (d->c_colsum) colsum_finalize(a, d->c_colsum, s);
+        if (d->c_colsum && !d->c_colsum_defer) colsum_finalize(a, d->c_colsum, s);
         OCC_LAUNCH_CHECK("occ_gemm");
         return OCC_OK;
     }
@@ -720,7 +720,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         g_last_kernel = OCC_GEMM_KERNEL_Q4;
         static const int q4_rows = getenv("OCC_Q4_ROWS") ? atoi(getenv("OCC_Q4_ROWS")) : 256;
         gemm_q4_launch(a, s, variant == 41 ? 224 : (variant == 40 ? 256 : q4_rows));
-        if (d->c_colsum) colsum_finalize(a, d->c_colsum, s);
+        if (d->c_colsum && !d->c_colsum_defer) colsum_finalize(a, d->c_colsum, s);
         OCC_LAUNCH_CHECK("occ_gemm");
         return OCC_OK;
     }
@@ -746,7 +746,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
             OCC_CHECK_ARG(can_224, "occ_gemm: the 224-row tile has no epilogue for this combination");
             g_last_kernel = OCC_GEMM_KERNEL_P8_224;
             gemm_p8_launch(a, s, 0, 224);
-            if (d->c_colsum) colsum_finalize(a, d->c_colsum, s);
+            if (d->c_colsum && !d->c_colsum_defer) colsum_finalize(a, d->c_colsum, s);
             OCC_LAUNCH_CHECK("occ_gemm");
             return OCC_OK;
         }
@@ -766,7 +766,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         }
         g_last_kernel = OCC_GEMM_KERNEL_P8;
         gemm_p8_launch(a, s);
-        if (d->c_colsum) colsum_finalize(a, d->c_colsum, s);
+        if (d->c_colsum && !d->c_colsum_defer) colsum_finalize(a, d->c_colsum, s);
         OCC_LAUNCH_CHECK("occ_gemm");
         return OCC_OK;
     }

@@ -503,6 +503,9 @@ class XlsrFineTuner(XlsrFrontend):
         self.inject_masks, self.inject_keep = None, None
         self.masks, self.keep = {}, None
         self._f8_pre = None                                      # (kind, site) of an fp8 operand a producing kernel has already written
+        # partial-sum finalizes of the backward pass in one launch (see _fin_site); OCC_DEFER_FINALIZE=0: one finalize launch per producer
+        self.defer_finalize = os.environ.get("OCC_DEFER_FINALIZE", "1") != "0"
+        self._fin_bufs, self._fin, self._fin_build = {}, {}, ops.FinalizeBatch()
         self.seed_layerdrop(0)
 
     def seed_layerdrop(self, seed):
@@ -772,14 +775,40 @@ class XlsrFineTuner(XlsrFrontend):
         f8 = getattr(self, "fp8", False) and f8_site is not None and not self.f8["warm"]
         if (bias_name is not None or f8) and M >= 2048 and C <= 1536:
             q = self._f8_buf(5, M * C) if f8 else None
-            ops.layernorm_bwd_fused(dy, x, self.w[gname + ".g"], dres, dx, self.mg[gname + ".g"], self.mg[gname + ".b"], dxb,
-                                    dbias=self.mg[bias_name] if bias_name is not None else None, dx_f8=q,
-                                    f8_scale=self.f8["scale5"][f8_site:f8_site + 1] if f8 else None, f8_amax=self.f8["amax5"][f8_site:f8_site + 1] if f8 else None)
+            dbias = self.mg[bias_name] if bias_name is not None else None
+            part = self._fin_site("ln." + gname, 768 * C)
+            ops.layernorm_bwd_fused(dy, x, self.w[gname + ".g"], dres, dx, self.mg[gname + ".g"], self.mg[gname + ".b"], dxb, dbias=dbias, dx_f8=q,
+                                    f8_scale=self.f8["scale5"][f8_site:f8_site + 1] if f8 else None, f8_amax=self.f8["amax5"][f8_site:f8_site + 1] if f8 else None,
+                                    defer=part)
+            if part is not None:
+                self._fin_build.add_ln(part, M, C, self.mg[gname + ".g"], self.mg[gname + ".b"], dbias)
             if f8:
                 self._f8_pre = (5, f8_site, 0)
             return bias_name is not None
         ops.layernorm_bwd(dy, x, self.w[gname + ".g"], dres, dx, self.mg[gname + ".g"], self.mg[gname + ".b"], dx_bf16=dxb)
         return False
+
+    # ---- deferred finalizes ----------------------------------------------------------------------------------------------
+    # The fused LayerNorm backward, the GELU' epilogue's column sums and the attention backward's bias sums leave per-workgroup partial sums;
+    # each site keeps them in a buffer of its own and ONE occ_finalize_batch launch adds them into the gradients -- at the end of the
+    # backward pass, or per layer when a data-parallel caller wants the layer's gradients final for its all-reduce (grad_ready).
+    def _fin_site(self, site, nfloats):
+        if not self.defer_finalize:
+            return None
+        buf = self._fin_bufs.get(site)
+        if buf is None or buf.numel() < nfloats:
+            buf = self._fin_bufs[site] = torch.empty(nfloats, device=self.device, dtype=torch.float32)
+        return buf
+
+    def _fin_flush(self, key):
+        if not self._fin_build.jobs:
+            return
+        fb = self._fin.get(key)
+        if fb is None:
+            fb = self._fin[key] = ops.FinalizeBatch()
+        fb.jobs, self._fin_build.jobs = self._fin_build.jobs, []
+        fb._refs, self._fin_build._refs = self._fin_build._refs, {}
+        fb.run()
 
     # ---- train-mode dropouts ---------------------------------------------------------------------------------------------
     def _p(self, field):
@@ -979,8 +1008,15 @@ class XlsrFineTuner(XlsrFrontend):
                 dyb = tr["dyb"]; self._drop_bwd("l%d.d3" % i, dxb, dyb, p_res)
             # fc1's bias gradient = column sums of du: from the same epilogue that writes du (large launches, no activation dropout on du)
             fc1_bias_fused = p_act == 0 and M * Fd >= 180 * 65536 and Fd % 8 == 0 and D % 64 == 0
+            colsum = None
+            if fc1_bias_fused:
+                colsum = self.mg["l%d.fc1.b" % i]
+                part = self._fin_site("fc1.%d" % i, 2 * ((M + 223) // 224) * Fd)
+                if part is not None:
+                    self._fin_build.add_rows(part, 2 * ((M + 223) // 224), colsum)
+                    colsum = (colsum, part)
             self._dgrad(i, "fc2.w", dyb, "g_fc2", M, Fd, D, tr["du"], act=ACT_MUL_AUX if KEEP_GELU_GRAD else ACT_GELU_GRAD, aux=s["u"], f8_next="g_fc1" if p_act == 0 else None,
-                        colsum=self.mg["l%d.fc1.b" % i] if fc1_bias_fused else None)
+                        colsum=colsum)
             if p_act > 0:                                        # (elementwise factors commute: mask after GELU')
                 self._drop_bwd("l%d.act" % i, tr["du"], tr["du"], p_act)
             # both FFN weight gradients in one launch (dyb is not rewritten before the LayerNorm backward below)
@@ -998,7 +1034,10 @@ class XlsrFineTuner(XlsrFrontend):
             if p_att > 0:
                 ops.attention_bwd_dropout(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, self.masks["l%d.att" % i], p_att, dqkv=tr["dqkv"])
             elif T <= 256:                                       # one key block: the kernel that writes dqkv also sums its columns (the qkv bias gradient)
-                ops.attention_bwd_bias(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, self.mg["l%d.qkv.b" % i], dqkv=tr["dqkv"])
+                part = self._fin_site("att.%d" % i, B * cfg.heads * 3 * hd)
+                ops.attention_bwd_bias(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, self.mg["l%d.qkv.b" % i], dqkv=tr["dqkv"], defer=part)
+                if part is not None:
+                    self._fin_build.add_attention_bias(part, B, cfg.heads, hd, self.mg["l%d.qkv.b" % i])
                 qkv_bias_done = True
             else:
                 ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
@@ -1011,7 +1050,9 @@ class XlsrFineTuner(XlsrFrontend):
             if j is not None:
                 fc2_bias_done[j] = done
             if grad_ready is not None:
+                self._fin_flush((M, i))                          # (also holds fc2.b of the layer below: final before that layer's own call)
                 grad_ready(*self.layer_grad_range(i))
+        self._fin_flush((M, "tail", grad_ready is not None))
         if p_res > 0:                                            # the encoder's input dropout
             self._drop_bwd("enc", dx, dx, p_res)
             self._drop_bwd("enc", dxb, dxb, p_res)

@@ -62,7 +62,11 @@ def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, 
     if c_f8 is not None:                       # (u8 buffer, scale scalar, amax scalar, fp8 format): fp8 copy of the bf16 result from the same epilogue
         d.c_f8, d.c_f8_scale, d.c_f8_amax, d.c_f8_fmt = c_f8[0].data_ptr(), c_f8[1].data_ptr(), c_f8[2].data_ptr(), int(c_f8[3])
     if c_colsum is not None:                   # f32 [N] += column sums of the bf16 result (bias gradient), from the same epilogue
-        ws = small_scratch(2 * ((int(M) + 223) // 224) * int(N))          # one partial row per 112-row half tile (occ_gemm checks the size)
+        if isinstance(c_colsum, tuple):        # (out, site scratch): partial sums only, the caller runs FinalizeBatch after the backward pass
+            c_colsum, ws = c_colsum
+            d.c_colsum_defer = 1
+        else:
+            ws = small_scratch(2 * ((int(M) + 223) // 224) * int(N))          # one partial row per 112-row half tile (occ_gemm checks the size)
         d.c_colsum, d.c_colsum_ws, d.c_colsum_ws_floats = c_colsum.data_ptr(), ws.data_ptr(), ws.numel()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -158,14 +162,15 @@ def attention_bwd(qkv, o, dout, lse, B, T, H, hd, scale, dqkv=None):
     return dqkv
 
 
-def attention_bwd_bias(qkv, o, dout, lse, B, T, H, hd, scale, dbias, dqkv=None):
-    """attention_bwd (T <= 256) that also adds the column sums of dqkv -- the q|k|v bias gradient -- into dbias f32 [3D]."""
+def attention_bwd_bias(qkv, o, dout, lse, B, T, H, hd, scale, dbias, dqkv=None, defer=None):
+    """attention_bwd (T <= 256) that also adds the column sums of dqkv -- the q|k|v bias gradient -- into dbias f32 [3D].
+    defer: this call site's own record buffer (>= B*H*3*hd floats): the per-(batch, head) sums stay there, no finalize launch (FinalizeBatch)."""
     D = H * hd
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
-    ws = small_scratch()
+    ws = defer if defer is not None else small_scratch()
     check(lib().occ_attention_bwd_bias(ptr(qkv), ptr(o), ptr(dout), ptr(lse), ptr(dqkv), B, T, H, hd, 3 * D, D, float(scale), ptr(dbias), ptr(ws), ws.numel(),
-                                       stream_ptr()), "occ_attention_bwd_bias")
+                                       1 if defer is not None else 0, stream_ptr()), "occ_attention_bwd_bias")
     return dqkv
 
 
@@ -336,14 +341,70 @@ def layernorm_fp8(x, gamma, beta, out, out_f8, f8_scale, f8_amax, eps=1e-5):
     return out
 
 
-def layernorm_bwd_fused(dy, x, gamma, dres, dx, dgamma, dbeta, dx_bf16, dbias=None, dx_f8=None, f8_scale=None, f8_amax=None, eps=1e-5):
-    """layernorm_bwd with the bias gradient of the preceding Linear (column sums of dx) and / or the e5m2 copy of the bf16 dx folded in."""
+def layernorm_bwd_fused(dy, x, gamma, dres, dx, dgamma, dbeta, dx_bf16, dbias=None, dx_f8=None, f8_scale=None, f8_amax=None, eps=1e-5, defer=None):
+    """layernorm_bwd with the bias gradient of the preceding Linear (column sums of dx) and / or the e5m2 copy of the bf16 dx folded in.
+    defer: a scratch tensor of this call site's own (>= 768 * C floats): the partial sums stay there, no finalize launch (FinalizeBatch)."""
     C = x.shape[-1]
     rows = x.numel() // C
-    sc = small_scratch(256 * 3 * C)
+    sc = defer if defer is not None else small_scratch(256 * 3 * C)
     check(lib().occ_layernorm_bwd_fused(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(dgamma), ptr(dbeta), ptr(dbias),
-                                        ptr(dx_f8), ptr(f8_scale), ptr(f8_amax), rows, C, float(eps), ptr(sc), sc.numel(), stream_ptr()), "occ_layernorm_bwd_fused")
+                                        ptr(dx_f8), ptr(f8_scale), ptr(f8_amax), rows, C, float(eps), ptr(sc), sc.numel(), 1 if defer is not None else 0, stream_ptr()),
+          "occ_layernorm_bwd_fused")
     return dx
+
+
+class FinalizeBatch:
+    """Job table for occ_finalize_batch: the partial sums that deferred producers (layernorm_bwd_fused(defer=), gemm_raw(c_colsum=(out, ws)),
+    attention_bwd_bias(defer=)) left in their per-site buffers are added into the gradients with ONE launch.  The table lives on the
+    device and is re-uploaded only when the list of jobs changes (it does not between steps of one shape)."""
+
+    def __init__(self):
+        self.jobs, self._key, self._dev, self._blocks = [], None, None, 0
+        self._refs = {}                        # data_ptr -> tensor: the table holds raw addresses, so it keeps their owners alive
+
+    def begin(self):
+        self.jobs = []
+
+    def _hold(self, *tensors):
+        for t in tensors:
+            if t is not None:
+                self._refs[t.data_ptr()] = t
+
+    def add_rows(self, partials, n_rows, out0, out1=None, out2=None, C=None):
+        """kind 0: out[i] += sum over n_rows rows of partials [n_rows, tot]; i < C -> out0, < 2C -> out1, else out2 (tot = C * number of outs given)."""
+        C = int(C if C is not None else out0.numel())
+        tot = C * (1 + (out1 is not None) + (out2 is not None))
+        if out2 is not None and out1 is None:
+            raise ValueError("out2 needs out1")
+        self._hold(partials, out0, out1, out2)
+        self.jobs.append((0, partials.data_ptr(), out0.data_ptr(), 0 if out1 is None else out1.data_ptr(), 0 if out2 is None else out2.data_ptr(), int(n_rows), tot, C,
+                          (tot + 63) // 64))
+
+    def add_ln(self, partials, rows, C, dgamma, dbeta, dbias):
+        """The fused LayerNorm backward's [block][3][C] partial sums (dbias may be None: the third set is then skipped by the sum)."""
+        n = min(256, (int(rows) + 47) // 48)
+        self._hold(partials, dgamma, dbeta, dbias)
+        self.jobs.append((0, partials.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0 if dbias is None else dbias.data_ptr(), n, 3 * int(C), int(C), (3 * int(C) + 63) // 64))
+
+    def add_attention_bias(self, records, B, H, hd, dbias):
+        self._hold(records, dbias)
+        self.jobs.append((1, records.data_ptr(), dbias.data_ptr(), 0, 0, int(B), int(H), int(hd), 3 * int(H)))
+
+    def run(self):
+        if not self.jobs:
+            return
+        key = tuple(self.jobs)
+        if key != self._key:
+            arr = (_lib.FinalizeJob * len(self.jobs))()
+            first = 0
+            for j, (kind, part, o0, o1, o2, n0, n1, n2, nb) in zip(arr, self.jobs):
+                j.partials, j.out0, j.out1, j.out2 = part, o0, o1 or None, o2 or None
+                j.kind, j.n0, j.n1, j.n2, j.first_block, j.n_blocks = kind, n0, n1, n2, first, nb
+                first += nb
+            raw = bytes(arr)
+            self._dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+            self._key, self._blocks, self._n = key, first, len(self.jobs)
+        check(lib().occ_finalize_batch(self._dev.data_ptr(), self._n, self._blocks, stream_ptr()), "occ_finalize_batch")
 
 
 # ---------------------------------------------------------------------------------- RawBoost ---

@@ -72,3 +72,44 @@ def test_hot_kernels_do_not_spill():
         assert hits, "no kernel matching %s in the build report" % want
         for k in hits:
             assert kernels[k]["ScratchSize"] == "0", "%s spills %s bytes per lane" % (k, kernels[k]["ScratchSize"])
+
+
+def test_ctypes_struct_mirrors_match_header(tmp_path):
+    """Every ctypes.Structure in occm_amd._lib mirrors a struct of include/occ_hip.h: same size and same field offsets as gcc lays them out
+    (a field added to the header but not to the mirror would silently shift everything behind it)."""
+    import ctypes
+    import re
+    import subprocess
+    from occm_amd import _lib
+    pairs = {"occ_rowmap": _lib.RowMap, "occ_gemm_desc": _lib.GemmDesc, "occ_finalize_job": _lib.FinalizeJob, "occ_gemm_tn_desc": _lib.GemmTnDesc,
+             "occ_master_desc": _lib.MasterDesc, "occ_master_grads": _lib.MasterGrads, "occ_readout_desc": _lib.ReadoutDesc, "occ_readout_grads": _lib.ReadoutGrads}
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "occ_hip.h")
+    text = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "%s"' % hdr, "int main(void) {"]
+    for cname, cls in pairs.items():
+        body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (cname, cname), text, flags=re.S)
+        assert body, cname
+        names = []
+        for decl in body.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            parts = decl.split(",")
+            first = re.search(r"(\w+)\s*(\[\w*\])?\s*$", parts[0]).group(1)
+            names += [first] + [re.search(r"(\w+)\s*(\[\w*\])?\s*$", p).group(1) for p in parts[1:]]
+        assert names == [f[0] for f in cls._fields_], (cname, names, [f[0] for f in cls._fields_])
+        lines.append('  printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        lines += ['  printf(" %%zu", offsetof(%s, %s));' % (cname, n) for n in names]
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    for line in out:
+        tok = line.split()
+        cls = pairs[tok[0]]
+        assert int(tok[1]) == ctypes.sizeof(cls), tok[0]
+        assert [int(t) for t in tok[2:]] == [getattr(cls, f[0]).offset for f in cls._fields_], tok[0]

@@ -617,3 +617,68 @@ def test_conv0_block_forward_and_backward_match_torch_autograd(B, L, dact_dt):
     for name, got, ref in zip(("dw", "dbias", "dgamma", "dbeta"), grads, (p.grad for p in pr)):
         d = (got.cpu().double() - 0.25 - ref).abs()
         assert float(d.max()) <= 2e-4 * float(ref.abs().max()) + 1e-4, (name, float(d.max()), float(ref.abs().max()))
+
+
+def test_deferred_finalizes_in_one_launch_equal_the_per_site_finalizes():
+    """occ_finalize_batch: the fused LayerNorm backward (defer), the GELU' epilogue's column sums (c_colsum_defer) and the attention
+    backward's bias sums (defer) leave their partial sums in per-site buffers; one launch over a job table of all three kinds adds them in
+    fixed orders (the LayerNorm and attention sums in the per-site kernels' own: bit-equal), also when accumulating onto what the buffers hold."""
+    from occm_amd import ops
+    from occm_amd._lib import ACT_GELU_GRAD, OCC_BF16
+    z = lambda *sh, dt=torch.float32: torch.zeros(*sh, device="cuda", dtype=dt)
+    fb = ops.FinalizeBatch()
+    checks = []
+    # two LayerNorm sites (one with a bias gradient in an odd place, one fp8-less without: third set skipped)
+    for C, rows, seed in ((1024, 2304 + 7, 2), (1280, 12736, 9), (512, 2048, 4)):
+        x = (_r(rows, C, seed=seed) * 2 + 0.3).cuda()
+        g = (1 + 0.1 * _r(C, seed=seed + 1)).cuda()
+        dy, dres = _r(rows, C, seed=seed + 2).bfloat16().cuda(), _r(rows, C, seed=seed + 3).cuda()
+        dx, dxb = z(rows, C), z(rows, C, dt=torch.bfloat16)
+        want = [torch.full((C,), 0.5, device="cuda") for _ in range(3)]
+        ops.layernorm_bwd_fused(dy, x, g, dres, dx, want[0], want[1], dxb, dbias=want[2])
+        got = [torch.full((C,), 0.5, device="cuda") for _ in range(3)]
+        part = torch.empty(768 * C, device="cuda")
+        dx1 = z(rows, C)
+        ops.layernorm_bwd_fused(dy, x, g, dres, dx1, got[0], got[1], dxb, dbias=got[2], defer=part)
+        assert torch.equal(dx1, dx) and all(float((t - 0.5).abs().max()) == 0 for t in got)          # nothing added yet
+        fb.add_ln(part, rows, C, *got)
+        checks += list(zip(got, want))
+    # the GELU' epilogue's column sums
+    M, N, K = 12736, 4096, 1024
+    gen = torch.Generator().manual_seed(4)
+    xa = (torch.randn(M, K, generator=gen) * 0.5).bfloat16().cuda(); w = (torch.randn(N, K, generator=gen) * K ** -0.5).bfloat16().cuda()
+    u = torch.randn(M, N, generator=gen).bfloat16().cuda()
+    Cm = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    run = lambda **kw: ops.gemm_raw(M, N, K, xa, ops.rowmap(M, 0, K), w, K, Cm, ops.rowmap(M, 0, N), OCC_BF16, OCC_BF16, act=ACT_GELU_GRAD, aux=u, **kw)
+    want = torch.full((N,), 0.25, device="cuda"); run(c_colsum=want)
+    got = torch.full((N,), 0.25, device="cuda")
+    part = torch.empty(2 * ((M + 223) // 224) * N, device="cuda")
+    run(c_colsum=(got, part))
+    fb.add_rows(part, 2 * ((M + 223) // 224), got)
+    checks.append((got, want))
+    # the attention backward's q|k|v bias sums
+    for B, T, H, hd in ((5, 199, 4, 64), (64, 199, 16, 64), (3, 61, 3, 80)):
+        D = H * hd
+        qkv, do = _r(B * T, 3 * D, seed=7).bfloat16().cuda(), _r(B * T, D, seed=8).bfloat16().cuda()
+        lse = torch.empty(B * H, T, device="cuda")
+        out = ops.attention(qkv, B, T, H, hd, hd ** -0.5, lse=lse)
+        want = torch.full((3 * D,), 0.125, device="cuda")
+        d0 = ops.attention_bwd_bias(qkv, out, do, lse, B, T, H, hd, hd ** -0.5, want)
+        got = torch.full((3 * D,), 0.125, device="cuda")
+        part = torch.empty(B * H * 3 * hd, device="cuda")
+        d1 = ops.attention_bwd_bias(qkv, out, do, lse, B, T, H, hd, hd ** -0.5, got, defer=part)
+        assert torch.equal(d0, d1)
+        fb.add_attention_bias(part, B, H, hd, got)
+        checks.append((got, want))
+    fb.run()
+    torch.cuda.synchronize()
+    for k, (got, want) in enumerate(checks):
+        assert float((want - 0.5).abs().max()) > 0
+        if got.numel() == 4096:                # the column sums: four waves take every fourth partial row (the per-site kernel walks them in order)
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-4)
+        else:
+            assert torch.equal(got, want), k
+    fb.run()                                   # the table is cached on the device: a second run adds the same sums again
+    for got, want in checks:
+        base = 0.5 if got.numel() in (1024, 1280, 512) else (0.25 if got.numel() == 4096 else 0.125)
+        torch.testing.assert_close(got - base, 2 * (want - base), rtol=1e-4, atol=1e-3)
