@@ -796,9 +796,19 @@ void launch_attention_mfma(const void* qkv, void* out, int B, int T, int H, long
 
 // f32-arithmetic attention (storage f32 or bf16): the whole-head kernel while K and V of a head fit in LDS, the streaming kernel beyond
 // (any T).  kv_len (optional, device int32 [B]): valid frames per utterance of a zero-padded batch.
+int occ_attention_f32_mfma_launch(const float* qkv, float* out, long long B, long long T, long long H, long long hd, long long ld_qkv, long long ld_out, float scale,
+                                  const int* kv_len, hipStream_t s);       // attention_f32.hip
+
 static int attention_f32_arith(const void* qkv, void* out, int dtype, int64_t B, int64_t T, int64_t H, int64_t hd, int64_t ld_qkv, int64_t ld_out,
                                float scale, const int32_t* kv_len, hipStream_t s) {
     if (dtype != OCC_F32 && dtype != OCC_BF16) { occ_set_error("occ_attention: dtype must be f32 or bf16"); return OCC_EUNSUPPORTED; }
+    // f32 storage, head dims 64 / 80 (XLS-R), 16-byte aligned rows: the f32 matrix cores (OCC_ATTN_F32_MFMA=0: the VALU kernels below)
+    static const int f32_mfma = getenv("OCC_ATTN_F32_MFMA") ? atoi(getenv("OCC_ATTN_F32_MFMA")) : 1;
+    if (f32_mfma && dtype == OCC_F32 && (hd == 64 || hd == 80) && ld_qkv % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+        occ_attention_f32_mfma_launch((const float*)qkv, (float*)out, B, T, H, hd, ld_qkv, ld_out, scale, kv_len, s);
+        OCC_LAUNCH_CHECK("occ_attention(f32 mfma)");
+        return OCC_OK;
+    }
     const size_t shm = ((size_t)2 * T * (hd + 1) + 4 * T + 4 * hd) * sizeof(float);
     hipError_t e;
     if (shm <= 160 * 1024) {
