@@ -505,7 +505,11 @@ class XlsrFineTuner(XlsrFrontend):
         self._f8_pre = None                                      # (kind, site) of an fp8 operand a producing kernel has already written
         # partial-sum finalizes of the backward pass in one launch (see _fin_site); OCC_DEFER_FINALIZE=0: one finalize launch per producer
         self.defer_finalize = os.environ.get("OCC_DEFER_FINALIZE", "1") != "0"
-        self._fin_bufs, self._fin, self._fin_build = {}, {}, ops.FinalizeBatch()
+        # the paired weight-gradient launches of the transformer layers on a second stream beside the input-gradient chain (see backward):
+        # measured +-0 inside the training step, so it is an option, off by default
+        self.overlap_wgrad = os.environ.get("OCC_WGRAD_STREAM", "0") == "1"
+        self._wg_stream = None
+        self._fin_bufs, self._fin_tags, self._fin, self._fin_build = {}, {}, {}, ops.FinalizeBatch()
         self.seed_layerdrop(0)
 
     def seed_layerdrop(self, seed):
@@ -640,6 +644,7 @@ class XlsrFineTuner(XlsrFrontend):
             # transposed operand buffers (pad columns stay zero) and gradient activations
             tr["dx"] = e(M, D, dt=f32)
             tr["dxb"] = e(M, D)                                   # bf16 copy of the residual-stream gradient (GEMM operand)
+            tr["dxb2"] = e(M, D)                                  # second copy: the two LayerNorm backwards of a layer alternate (weight gradients on a side stream)
             tr["du"], tr["dh"], tr["da"], tr["dqkv"] = e(M, Fd), e(M, D), e(M, D), e(M, 3 * D)
             ws["tr"] = tr
         return ws
@@ -792,12 +797,19 @@ class XlsrFineTuner(XlsrFrontend):
     # The fused LayerNorm backward, the GELU' epilogue's column sums and the attention backward's bias sums leave per-workgroup partial sums;
     # each site keeps them in a buffer of its own and ONE occ_finalize_batch launch adds them into the gradients -- at the end of the
     # backward pass, or per layer when a data-parallel caller wants the layer's gradients final for its all-reduce (grad_ready).
-    def _fin_site(self, site, nfloats):
+    def _fin_site(self, site, nfloats, zero_tag=None):
+        """This site's partial-sum buffer.  zero_tag (the GELU' column sums): the producer may write FEWER partial rows than the job sums --
+        occ_gemm picks 224- or 256-row tiles, the job counts rows for the smaller -- so the buffer starts as zeros and is cleared again
+        whenever the launch shape (zero_tag) changes: rows the kernel of one shape never writes then always read as zero."""
         if not self.defer_finalize:
             return None
         buf = self._fin_bufs.get(site)
         if buf is None or buf.numel() < nfloats:
-            buf = self._fin_bufs[site] = torch.empty(nfloats, device=self.device, dtype=torch.float32)
+            buf = self._fin_bufs[site] = (torch.zeros if zero_tag is not None else torch.empty)(nfloats, device=self.device, dtype=torch.float32)
+            self._fin_tags[site] = zero_tag
+        elif zero_tag is not None and self._fin_tags.get(site) != zero_tag:
+            buf.zero_()
+            self._fin_tags[site] = zero_tag
         return buf
 
     def _fin_flush(self, key):
@@ -988,6 +1000,38 @@ class XlsrFineTuner(XlsrFrontend):
         # ln1: fc2 of the next kept layer down; ln2: this layer's out-proj): with no residual dropout in between that kernel also produces the
         # Linear's bias gradient and, on the fp8 path, its e5m2 GEMM operand.
         fuse = p_res == 0
+        # Weight gradients beside the input-gradient chain.  Every large launch here owns whole CUs (128 KiB of LDS or all registers), and
+        # the input-gradient GEMMs leave CUs idle: 228 tiles for 256 CUs at N = 1024, a 0.56-full last round at N = 4096, and their epilogues
+        # stall the matrix cores.  The two paired weight-gradient launches of a layer depend only on operands the chain has already
+        # produced, so they can go to a second stream and fill those holes (scripts/bench_two_streams.py, GEMMs only: 690 -> 628 us per
+        # layer; inside the whole step, with the LayerNorm / attention backward kernels in the chain: +-0.2 ms either way).  Hazards:
+        # a pair reads the bf16 residual gradient of ITS LayerNorm backward, du / dqkv and saved activations; the two LayerNorm backwards
+        # of a layer therefore write alternate bf16 buffers (A: enc_ln / ln1, B: ln2), and the main stream waits for the FFN pair
+        # before ln1 rewrites A (and, one layer on, du) and for the attention pair before the next ln2 / attention backward rewrite B / dqkv.
+        # Not with residual / activation / attention dropout (their gradient buffers are reused within the layer), not while a caller
+        # wants per-layer gradients (grad_ready: the data-parallel all-reduce), not under stream capture.
+        side = None
+        if self.overlap_wgrad and grad_ready is None and p_res == 0 and p_act == 0 and p_att == 0 and not torch.cuda.is_current_stream_capturing():
+            if self._wg_stream is None:
+                self._wg_stream = torch.cuda.Stream(device=self.device)
+            side = self._wg_stream
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+        dxbA, dxbB = tr["dxb"], (tr["dxb2"] if side is not None else tr["dxb"])
+        ffn_done = att_done = None                               # events: the side stream has finished the layer's FFN / attention pair
+
+        def on_side(fn, after_main=True):
+            """Run fn (a weight-gradient pair) on the side stream once the main stream has reached this point; returns its completion event."""
+            if side is None:
+                fn()
+                return None
+            ready = torch.cuda.Event(); ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                fn()
+                done = torch.cuda.Event(); done.record(side)
+            return done
+
         kept = [i for i in range(cfg.layers) if self.keep[i]]
         below = lambda i: max([j for j in kept if j < i], default=None)      # the kept layer whose output gradient ln1-backward of layer i produces
         top = kept[-1] if kept else None
@@ -1003,15 +1047,15 @@ class XlsrFineTuner(XlsrFrontend):
                     grad_ready(*self.layer_grad_range(i))
                 continue
             # ---- FFN: x3 = x_mid + dropout3(fc2(dropout2(gelu(fc1(LN2(x_mid))))))
-            dyb = dxb
+            dyb = dxbA
             if p_res > 0:
-                dyb = tr["dyb"]; self._drop_bwd("l%d.d3" % i, dxb, dyb, p_res)
+                dyb = tr["dyb"]; self._drop_bwd("l%d.d3" % i, dxbA, dyb, p_res)
             # fc1's bias gradient = column sums of du: from the same epilogue that writes du (large launches, no activation dropout on du)
             fc1_bias_fused = p_act == 0 and M * Fd >= 180 * 65536 and Fd % 8 == 0 and D % 64 == 0
             colsum = None
             if fc1_bias_fused:
                 colsum = self.mg["l%d.fc1.b" % i]
-                part = self._fin_site("fc1.%d" % i, 2 * ((M + 223) // 224) * Fd)
+                part = self._fin_site("fc1.%d" % i, 2 * ((M + 223) // 224) * Fd, zero_tag=(M, Fd, D, bool(getattr(self, "fp8", False))))
                 if part is not None:
                     self._fin_build.add_rows(part, 2 * ((M + 223) // 224), colsum)
                     colsum = (colsum, part)
@@ -1020,15 +1064,17 @@ class XlsrFineTuner(XlsrFrontend):
             if p_act > 0:                                        # (elementwise factors commute: mask after GELU')
                 self._drop_bwd("l%d.act" % i, tr["du"], tr["du"], p_act)
             # both FFN weight gradients in one launch (dyb is not rewritten before the LayerNorm backward below)
-            self._wgrad_pair(M, (dyb, s["f"], D, Fd, "l%d.fc2.w" % i, None if fc2_bias_done.get(i) else "l%d.fc2.b" % i),
-                             (tr["du"], s["h2"], Fd, D, "l%d.fc1.w" % i, None if fc1_bias_fused else "l%d.fc1.b" % i))
+            ffn_done = on_side(lambda dyb=dyb, s=s, i=i, b2=fc2_bias_done.get(i), b1=fc1_bias_fused: self._wgrad_pair(
+                M, (dyb, s["f"], D, Fd, "l%d.fc2.w" % i, None if b2 else "l%d.fc2.b" % i), (tr["du"], s["h2"], Fd, D, "l%d.fc1.w" % i, None if b1 else "l%d.fc1.b" % i)))
             self._dgrad(i, "fc1.w", tr["du"], "g_fc1", M, D, Fd, tr["dh"])
-            o_bias_done = self._ln_bwd(tr["dh"], s["x_mid"], "l%d.ln2" % i, dx, dx, dxb, bias_name="l%d.o.b" % i if fuse else None,
+            if att_done is not None:                             # the layer above's attention pair still reads buffer B (and dqkv)
+                main.wait_event(att_done); att_done = None
+            o_bias_done = self._ln_bwd(tr["dh"], s["x_mid"], "l%d.ln2" % i, dx, dx, dxbB, bias_name="l%d.o.b" % i if fuse else None,
                                        f8_site=i * 4 + self._E5["g_o"] if fuse else None)
             # ---- attention: x_mid = x_in + dropout1(out_proj(attn(qkv(LN1(x_in)))))
-            dyb = dxb
+            dyb = dxbB
             if p_res > 0:
-                dyb = tr["dyb"]; self._drop_bwd("l%d.d1" % i, dxb, dyb, p_res)
+                dyb = tr["dyb"]; self._drop_bwd("l%d.d1" % i, dxbB, dyb, p_res)
             self._dgrad(i, "o.w", dyb, "g_o", M, D, D, tr["da"])
             qkv_bias_done = False
             if p_att > 0:
@@ -1041,17 +1087,21 @@ class XlsrFineTuner(XlsrFrontend):
                 qkv_bias_done = True
             else:
                 ops.attention_bwd(s["qkv"], s["att"], tr["da"], s["lse"], B, T, cfg.heads, hd, hd ** -0.5, dqkv=tr["dqkv"])
-            self._wgrad_pair(M, (dyb, s["att"], D, D, "l%d.o.w" % i, None if o_bias_done else "l%d.o.b" % i),
-                             (tr["dqkv"], s["h1"], 3 * D, D, "l%d.qkv.w" % i, None if qkv_bias_done else "l%d.qkv.b" % i))
+            att_done = on_side(lambda dyb=dyb, s=s, i=i, bo=o_bias_done, bq=qkv_bias_done: self._wgrad_pair(
+                M, (dyb, s["att"], D, D, "l%d.o.w" % i, None if bo else "l%d.o.b" % i), (tr["dqkv"], s["h1"], 3 * D, D, "l%d.qkv.w" % i, None if bq else "l%d.qkv.b" % i)))
             self._dgrad(i, "qkv.w", tr["dqkv"], "g_qkv", M, D, 3 * D, tr["dh"])
             j = below(i)
-            done = self._ln_bwd(tr["dh"], s["x_in"], "l%d.ln1" % i, dx, dx, dxb, bias_name="l%d.fc2.b" % j if fuse and j is not None else None,
+            if ffn_done is not None:                             # this layer's FFN pair still reads buffer A (and du)
+                main.wait_event(ffn_done); ffn_done = None
+            done = self._ln_bwd(tr["dh"], s["x_in"], "l%d.ln1" % i, dx, dx, dxbA, bias_name="l%d.fc2.b" % j if fuse and j is not None else None,
                                 f8_site=j * 4 + self._E5["g_fc2"] if fuse and j is not None else None)
             if j is not None:
                 fc2_bias_done[j] = done
             if grad_ready is not None:
                 self._fin_flush((M, i))                          # (also holds fc2.b of the layer below: final before that layer's own call)
                 grad_ready(*self.layer_grad_range(i))
+        if side is not None:
+            main.wait_stream(side)                               # every weight gradient is in G (the optimizer and the conv stack's backward follow)
         self._fin_flush((M, "tail", grad_ready is not None))
         if p_res > 0:                                            # the encoder's input dropout
             self._drop_bwd("enc", dx, dx, p_res)

@@ -371,7 +371,9 @@ class FinalizeBatch:
                 self._refs[t.data_ptr()] = t
 
     def add_rows(self, partials, n_rows, out0, out1=None, out2=None, C=None):
-        """kind 0: out[i] += sum over n_rows rows of partials [n_rows, tot]; i < C -> out0, < 2C -> out1, else out2 (tot = C * number of outs given)."""
+        """kind 0: out[i] += sum over n_rows rows of partials [n_rows, tot]; i < C -> out0, < 2C -> out1, else out2 (tot = C * number of outs given).
+        For gemm_raw(c_colsum=(out, ws)) pass n_rows = 2 * ceil(M / 224) and a ws that started as ZEROS: occ_gemm writes 2 * ceil(M / tile rows)
+        partial rows with 224- or 256-row tiles (its own choice per shape); the rows it does not write must read as zero."""
         C = int(C if C is not None else out0.numel())
         tot = C * (1 + (out1 is not None) + (out2 is not None))
         if out2 is not None and out1 is None:

@@ -644,18 +644,19 @@ def test_deferred_finalizes_in_one_launch_equal_the_per_site_finalizes():
         fb.add_ln(part, rows, C, *got)
         checks += list(zip(got, want))
     # the GELU' epilogue's column sums
-    M, N, K = 12736, 4096, 1024
-    gen = torch.Generator().manual_seed(4)
-    xa = (torch.randn(M, K, generator=gen) * 0.5).bfloat16().cuda(); w = (torch.randn(N, K, generator=gen) * K ** -0.5).bfloat16().cuda()
-    u = torch.randn(M, N, generator=gen).bfloat16().cuda()
-    Cm = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    run = lambda **kw: ops.gemm_raw(M, N, K, xa, ops.rowmap(M, 0, K), w, K, Cm, ops.rowmap(M, 0, N), OCC_BF16, OCC_BF16, act=ACT_GELU_GRAD, aux=u, **kw)
-    want = torch.full((N,), 0.25, device="cuda"); run(c_colsum=want)
-    got = torch.full((N,), 0.25, device="cuda")
-    part = torch.empty(2 * ((M + 223) // 224) * N, device="cuda")
-    run(c_colsum=(got, part))
-    fb.add_rows(part, 2 * ((M + 223) // 224), got)
-    checks.append((got, want))
+    # (224-row tiles at bs 64; 256-row tiles -- fewer partial rows than the job counts -- at configs[4]'s shard)
+    for M, N, K in ((12736, 4096, 1024), (6368, 5120, 1280)):
+        gen = torch.Generator().manual_seed(4)
+        xa = (torch.randn(M, K, generator=gen) * 0.5).bfloat16().cuda(); w = (torch.randn(N, K, generator=gen) * K ** -0.5).bfloat16().cuda()
+        u = torch.randn(M, N, generator=gen).bfloat16().cuda()
+        Cm = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        run = lambda **kw: ops.gemm_raw(M, N, K, xa, ops.rowmap(M, 0, K), w, K, Cm, ops.rowmap(M, 0, N), OCC_BF16, OCC_BF16, act=ACT_GELU_GRAD, aux=u, **kw)
+        want = torch.full((N,), 0.25, device="cuda"); run(c_colsum=want)
+        got = torch.full((N,), 0.25, device="cuda")
+        part = torch.zeros(2 * ((M + 223) // 224) * N, device="cuda")            # zeros: the launch may write fewer rows than the job sums (256-row tiles)
+        run(c_colsum=(got, part))
+        fb.add_rows(part, 2 * ((M + 223) // 224), got)
+        checks.append((got, want))
     # the attention backward's q|k|v bias sums
     for B, T, H, hd in ((5, 199, 4, 64), (64, 199, 16, 64), (3, 61, 3, 80)):
         D = H * hd
@@ -674,11 +675,46 @@ def test_deferred_finalizes_in_one_launch_equal_the_per_site_finalizes():
     torch.cuda.synchronize()
     for k, (got, want) in enumerate(checks):
         assert float((want - 0.5).abs().max()) > 0
-        if got.numel() == 4096:                # the column sums: four waves take every fourth partial row (the per-site kernel walks them in order)
+        if got.numel() in (4096, 5120):        # the column sums: four waves take every fourth partial row (the per-site kernel walks them in order)
             torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-4)
         else:
             assert torch.equal(got, want), k
     fb.run()                                   # the table is cached on the device: a second run adds the same sums again
     for got, want in checks:
-        base = 0.5 if got.numel() in (1024, 1280, 512) else (0.25 if got.numel() == 4096 else 0.125)
+        base = 0.5 if got.numel() in (1024, 1280, 512) else (0.25 if got.numel() in (4096, 5120) else 0.125)
         torch.testing.assert_close(got - base, 2 * (want - base), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,L", [(2, 4000), (12, 64000)])
+def test_weight_gradients_on_a_side_stream_equal_the_one_stream_backward(B, L):
+    """XlsrFineTuner.overlap_wgrad (OCC_WGRAD_STREAM=1): the paired weight-gradient launches of every layer run on a second stream, the two
+    LayerNorm backwards of a layer alternate their bf16 output buffers, events guard every buffer a pair still reads.  Same kernels on the
+    same operands: every gradient equals the one-stream backward's (a missed hazard would show as a gross difference in some layer)."""
+    from oracle import xlsr_ref
+    from oracle.fill import fill_like
+    from occm_amd.models import xlsr
+    kw = dict(dim=256, ffn=512, heads=4, layers=4)
+    cfg = xlsr.XlsrConfig(**kw)
+    p = fill_like(xlsr_ref.param_shapes(xlsr_ref.XlsrConfig(**kw)), seed=3)
+    ft = xlsr.XlsrFullFineTuner(p, cfg)
+    wav = (0.1 * _r(B, L, seed=5)).cuda()
+    grads = []
+    for overlap in (False, False, True, True):
+        ft.overlap_wgrad = overlap
+        out = ft.forward_train(wav)
+        dfe = _r(*out.shape, seed=6).cuda()
+        ft.zero_grad()
+        ft.backward(dfe)
+        torch.cuda.synchronize()
+        grads.append(ft.G.clone())
+    assert ft._wg_stream is not None and float(grads[0].abs().max()) > 0
+    # run-to-run noise of the one-stream backward itself (split-K / conv-stack kernels add with f32 atomics at these sizes)
+    scale = float(grads[0].abs().max())
+    noise = float((grads[1] - grads[0]).abs().max())
+    assert noise <= 1e-4 * scale
+    for g in grads[2:]:
+        assert float((g - grads[0]).abs().max()) <= 8 * noise + 1e-6 * scale
+        for i in range(cfg.layers):                                     # and layer by layer (a stale operand would spoil one layer's tensors wholesale)
+            lo, hi = ft.layer_grad_range(i)
+            a, b = g[lo:hi].double(), grads[0][lo:hi].double()
+            assert float((a * b).sum() / (a.norm() * b.norm())) > 1 - 1e-9
