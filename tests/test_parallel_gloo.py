@@ -20,7 +20,7 @@ def _worker(rank, world, port, out):
     flat = torch.randn(1000, generator=g)
     local = flat.clone()
     red = parallel.FlatGradAllReducer(flat, bucket_bytes=1024)          # 4 buckets of 256 floats
-    assert len(red.buckets) == 4 and red.grad_scale == 0.5
+    assert len(red.buckets) == 4 and red.grad_scale == 1.0 / world
     red.all_reduce()
     expect = sum(torch.randn(1000, generator=torch.Generator().manual_seed(100 + k)) for k in range(world))
     ok = torch.allclose(flat, expect, atol=1e-6)
@@ -44,7 +44,7 @@ def _worker(rank, world, port, out):
     two = torch.randn(1000, generator=torch.Generator().manual_seed(100 + rank))
     r3 = parallel.FlatGradAllReducer(two, bucket_bytes=400)
     r3.reduce_range(900, 1000); r3.reduce_range(0, 250); r3.all_reduce()
-    ok = ok and torch.equal(one, two)
+    ok = ok and (torch.equal(one, two) if world == 2 else torch.allclose(one, two, atol=1e-5))       # (more ranks: gloo's ring order per bucket size)
     # bf16 on the wire (half the payload): equals the f32 exchange to bf16 round-off of the summands and of the sum; results land in
     # the f32 buffer; overlapped slices and the remainder are all widened back exactly once
     wb = torch.randn(1000, generator=torch.Generator().manual_seed(100 + rank))
@@ -54,7 +54,7 @@ def _worker(rank, world, port, out):
     ok = ok and wb.dtype == torch.float32 and r4._pending == [] and bool(((wb - expect).abs() <= 2.0 ** -7 * (expect.abs() + 4.0)).all())
     ok = ok and not torch.equal(wb, expect)                              # (it really went through bf16)
     exact = sum(torch.randn(1000, generator=torch.Generator().manual_seed(100 + k)).bfloat16() for k in range(world)).float()
-    ok = ok and torch.equal(wb, exact)                                   # two ranks: bf16(a) + bf16(b) rounded once to bf16
+    ok = ok and (torch.equal(wb, exact) if world == 2 else True)         # two ranks: bf16(a) + bf16(b) rounded once to bf16 (more ranks round per partial sum)
     mx = parallel.max_over_ranks(1.5 + rank, torch.device("cpu"))
     lo, hi = parallel.shard_groups(5, rank, world)
     parallel.barrier()
@@ -76,6 +76,25 @@ def test_flat_grad_allreduce_world2():
     assert [r[1] for r in res] == [True, True]
     assert [r[2] for r in res] == [2.5, 2.5]
     assert [r[3] for r in res] == [(0, 3), (3, 5)]          # 5 groups over 2 ranks: contiguous, none split
+
+
+def test_flat_grad_allreduce_world4():
+    """The same exchange over four ranks (the largest world the 8-core container rehearses): sums of four ranks' gradients in the f32,
+    overlapped and bf16-wire forms, grad_scale 1/4, five layer groups dealt 2 / 1 / 1 / 1."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True] * 4
+    assert [r[2] for r in res] == [4.5] * 4
+    spans = [r[3] for r in res]
+    assert spans[0][0] == 0 and spans[-1][1] == 5 and all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and all(hi > lo for lo, hi in spans)
 
 
 def test_shard_groups_covers_everything_once():
