@@ -23,6 +23,14 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(3))) void lds_void;
 
+// two floats -> one dword of bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32 (the scalar conversions or-ed together cost four instructions a pair)
+typedef __attribute__((ext_vector_type(2))) float ab_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 ab_bf16x2;
+__device__ __forceinline__ unsigned ab_pack2(float lo, float hi) {
+    const ab_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ab_bf16x2));
+}
+
 __device__ __forceinline__ u32x2 ab_tr_read(unsigned addr) {
     u32x2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
@@ -260,7 +268,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     [[maybe_unused]] const int ql = qt * 16 + g * 4 + r;
-                    const float p = key < nkeys ? __builtin_amdgcn_exp2f(sacc[r] * c2 - lq[qt][r]) : 0.f;
+                    // (one fused multiply-add for the exponent's argument; head dim 80 keeps the two-instruction form: the fused one spilled two registers there)
+                    const float ea = HD == 64 ? fmaf(sacc[r], c2, -lq[qt][r]) : sacc[r] * c2 - lq[qt][r];
+                    const float p = key < nkeys ? __builtin_amdgcn_exp2f(ea) : 0.f;
                     float pd = p, dpd = dpacc[r];
                     if constexpr (DROP) {
                         const int qg = q0 + ql < Tn ? q0 + ql : Tn - 1, kg = key < nkeys ? key0 + key : Tn - 1;
@@ -273,10 +283,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                pp[kk][e] = (unsigned)f32_to_bf16_bits(pv[0][2 * e]) | ((unsigned)f32_to_bf16_bits(pv[0][2 * e + 1]) << 16);
-                pp[kk][2 + e] = (unsigned)f32_to_bf16_bits(pv[1][2 * e]) | ((unsigned)f32_to_bf16_bits(pv[1][2 * e + 1]) << 16);
-                ds[kk][e] = (unsigned)f32_to_bf16_bits(dsv[0][2 * e]) | ((unsigned)f32_to_bf16_bits(dsv[0][2 * e + 1]) << 16);
-                ds[kk][2 + e] = (unsigned)f32_to_bf16_bits(dsv[1][2 * e]) | ((unsigned)f32_to_bf16_bits(dsv[1][2 * e + 1]) << 16);
+                pp[kk][e] = ab_pack2(pv[0][2 * e], pv[0][2 * e + 1]);
+                pp[kk][2 + e] = ab_pack2(pv[1][2 * e], pv[1][2 * e + 1]);
+                ds[kk][e] = ab_pack2(dsv[0][2 * e], dsv[0][2 * e + 1]);
+                ds[kk][2 + e] = ab_pack2(dsv[1][2 * e], dsv[1][2 * e + 1]);
             }
             // dS^T[key][queries 4g .. 4g+3 of q-tile qt]: the packed pairs as they are
             // ((key >> 2) & 1 = (fr >> 2) & 1: the two halves' places are lane constants)
