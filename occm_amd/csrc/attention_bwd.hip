@@ -23,14 +23,6 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(3))) void lds_void;
 
-// two floats -> one dword of bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32 (the scalar conversions or-ed together cost four instructions a pair)
-typedef __attribute__((ext_vector_type(2))) float ab_f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 ab_bf16x2;
-__device__ __forceinline__ unsigned ab_pack2(float lo, float hi) {
-    const ab_f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ab_bf16x2));
-}
-
 __device__ __forceinline__ u32x2 ab_tr_read(unsigned addr) {
     u32x2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
@@ -218,8 +210,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
             if (q < Tn) {
                 if (gridDim.y == 1) {
                     uint2 ov;
-                    ov.x = (unsigned)f32_to_bf16_bits(qacc[0] * scale) | ((unsigned)f32_to_bf16_bits(qacc[1] * scale) << 16);
-                    ov.y = (unsigned)f32_to_bf16_bits(qacc[2] * scale) | ((unsigned)f32_to_bf16_bits(qacc[3] * scale) << 16);
+                    ov.x = pack_bf16x2(qacc[0] * scale, qacc[1] * scale);
+                    ov.y = pack_bf16x2(qacc[2] * scale, qacc[3] * scale);
                     *reinterpret_cast<uint2*>(dqkv + ((size_t)b * Tn + q) * ld_qkv + (size_t)h * HD + dt * 16 + g * 4) = ov;
                     if (BIAS) {
                         dqs[slot & 1][0] += __uint_as_float(ov.x << 16); dqs[slot & 1][1] += __uint_as_float(ov.x & 0xffff0000u);
@@ -283,10 +275,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                pp[kk][e] = ab_pack2(pv[0][2 * e], pv[0][2 * e + 1]);
-                pp[kk][2 + e] = ab_pack2(pv[1][2 * e], pv[1][2 * e + 1]);
-                ds[kk][e] = ab_pack2(dsv[0][2 * e], dsv[0][2 * e + 1]);
-                ds[kk][2 + e] = ab_pack2(dsv[1][2 * e], dsv[1][2 * e + 1]);
+                pp[kk][e] = pack_bf16x2(pv[0][2 * e], pv[0][2 * e + 1]);
+                pp[kk][2 + e] = pack_bf16x2(pv[1][2 * e], pv[1][2 * e + 1]);
+                ds[kk][e] = pack_bf16x2(dsv[0][2 * e], dsv[0][2 * e + 1]);
+                ds[kk][2 + e] = pack_bf16x2(dsv[1][2 * e], dsv[1][2 * e + 1]);
             }
             // dS^T[key][queries 4g .. 4g+3 of q-tile qt]: the packed pairs as they are
             // ((key >> 2) & 1 = (fr >> 2) & 1: the two halves' places are lane constants)
@@ -347,10 +339,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd2_kernel(const unsigned s
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             uint2 kk2, vv;
-            kk2.x = (unsigned)f32_to_bf16_bits(dkacc[dt][kk][0] * scale) | ((unsigned)f32_to_bf16_bits(dkacc[dt][kk][1] * scale) << 16);
-            kk2.y = (unsigned)f32_to_bf16_bits(dkacc[dt][kk][2] * scale) | ((unsigned)f32_to_bf16_bits(dkacc[dt][kk][3] * scale) << 16);
-            vv.x = (unsigned)f32_to_bf16_bits(dvacc[dt][kk][0]) | ((unsigned)f32_to_bf16_bits(dvacc[dt][kk][1]) << 16);
-            vv.y = (unsigned)f32_to_bf16_bits(dvacc[dt][kk][2]) | ((unsigned)f32_to_bf16_bits(dvacc[dt][kk][3]) << 16);
+            kk2.x = pack_bf16x2(dkacc[dt][kk][0] * scale, dkacc[dt][kk][1] * scale);
+            kk2.y = pack_bf16x2(dkacc[dt][kk][2] * scale, dkacc[dt][kk][3] * scale);
+            vv.x = pack_bf16x2(dvacc[dt][kk][0], dvacc[dt][kk][1]);
+            vv.y = pack_bf16x2(dvacc[dt][kk][2], dvacc[dt][kk][3]);
             *reinterpret_cast<uint2*>(dkrow + dt * 16 + g * 4) = kk2;
             *reinterpret_cast<uint2*>(dvrow + dt * 16 + g * 4) = vv;
             if (BIAS) {
@@ -436,8 +428,8 @@ __global__ void attention_dq_finish_kernel(const float* __restrict__ acc, unsign
         const long long r = i / (D / 4); const int c = (int)(i - r * (D / 4)) * 4;
         const float4 v = *reinterpret_cast<const float4*>(acc + r * D + c);
         uint2 ov;
-        ov.x = (unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16);
-        ov.y = (unsigned)f32_to_bf16_bits(v.z) | ((unsigned)f32_to_bf16_bits(v.w) << 16);
+        ov.x = pack_bf16x2(v.x, v.y);
+        ov.y = pack_bf16x2(v.z, v.w);
         *reinterpret_cast<uint2*>(dqkv + r * ld_qkv + c) = ov;
     }
 }

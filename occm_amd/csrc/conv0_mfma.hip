@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
                         const int blk = q4 * 4 + u;
                         const float y0 = gelu_erf((acc[blk][e] - mean[e]) * rstd[e] * gg[u] + bb[u]);
                         const float y1 = gelu_erf((acc[blk + 1][e] - mean[e]) * rstd[e] * gg[u + 1] + bb[u + 1]);
-                        pk[blk >> 1] = (unsigned)f32_to_bf16_bits(y0) | ((unsigned)f32_to_bf16_bits(y1) << 16);
+                        pk[blk >> 1] = pack_bf16x2(y0, y1);
                     }
                 }
                 uint4* row = tile + (2 * g + eh) * 64 + c * 4;

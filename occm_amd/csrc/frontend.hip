@@ -29,7 +29,7 @@ template <> struct Vec8<unsigned short> {
     static __device__ __forceinline__ void store(unsigned short* p, const float (&v)[8]) {
         unsigned w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
@@ -465,8 +465,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
         unsigned pw[4];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            pw[e] = (unsigned)f32_to_bf16_bits(sc[2 * u][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u][2 * e + 1]) << 16);
-            pw[2 + e] = (unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e + 1]) << 16);
+            pw[e] = pack_bf16x2(sc[2 * u][2 * e], sc[2 * u][2 * e + 1]);
+            pw[2 + e] = pack_bf16x2(sc[2 * u + 1][2 * e], sc[2 * u + 1][2 * e + 1]);
         }
         uint4 pf = make_uint4(pw[0], pw[1], pw[2], pw[3]);
 #pragma unroll
@@ -605,8 +605,8 @@ __global__ __launch_bounds__(256) void attention_mfma_long_kernel(const unsigned
             unsigned pw[4];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                pw[e] = (unsigned)f32_to_bf16_bits(sc[2 * u][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u][2 * e + 1]) << 16);
-                pw[2 + e] = (unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e + 1]) << 16);
+                pw[e] = pack_bf16x2(sc[2 * u][2 * e], sc[2 * u][2 * e + 1]);
+                pw[2 + e] = pack_bf16x2(sc[2 * u + 1][2 * e], sc[2 * u + 1][2 * e + 1]);
             }
             uint4 pf = make_uint4(pw[0], pw[1], pw[2], pw[3]);
 #pragma unroll
@@ -740,8 +740,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
             unsigned pw[4];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                pw[e] = (unsigned)f32_to_bf16_bits(sc[2 * u][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u][2 * e + 1]) << 16);
-                pw[2 + e] = (unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e]) | ((unsigned)f32_to_bf16_bits(sc[2 * u + 1][2 * e + 1]) << 16);
+                pw[e] = pack_bf16x2(sc[2 * u][2 * e], sc[2 * u][2 * e + 1]);
+                pw[2 + e] = pack_bf16x2(sc[2 * u + 1][2 * e], sc[2 * u + 1][2 * e + 1]);
             }
             uint4 pf = make_uint4(pw[0], pw[1], pw[2], pw[3]);
 #pragma unroll

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
                 if (dx_bf16) {
                     unsigned w[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+                    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
                     *reinterpret_cast<uint4*>(dx_bf16 + row_off(bmap, row) + c) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * WAVES) void layernorm_bwd16_kernel(const TDY* 
                 if (dx_bf16) {
                     unsigned w[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+                    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
                     *reinterpret_cast<uint4*>(dx_bf16 + row_off(bmap, row) + c) = make_uint4(w[0], w[1], w[2], w[3]);
                     if (EXTRA && ex.f8) {           // e5m2 of the bf16-rounded values (what the stand-alone quantisation pass reads), saturating
                         float qv[8];
@@ -491,8 +491,8 @@ __global__ void gelu_bwd_rows_kernel(const float* __restrict__ dy, const unsigne
         const float v0 = d.x * gelu_grad(bf16_bits_to_f32((unsigned short)(uu.x & 0xffff))), v1 = d.y * gelu_grad(bf16_bits_to_f32((unsigned short)(uu.x >> 16)));
         const float v2 = d.z * gelu_grad(bf16_bits_to_f32((unsigned short)(uu.y & 0xffff))), v3 = d.w * gelu_grad(bf16_bits_to_f32((unsigned short)(uu.y >> 16)));
         uint2 o;
-        o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
-        o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
+        o.x = pack_bf16x2(v0, v1);
+        o.y = pack_bf16x2(v2, v3);
         *reinterpret_cast<uint2*>(out + row_off(omap, r) + c) = o;
     }
 }

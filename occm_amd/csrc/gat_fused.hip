@@ -22,7 +22,7 @@ typedef __attribute__((ext_vector_type(4))) float gf32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 gbf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned gu32x4;
 
-__device__ __forceinline__ unsigned gpack2(float a, float b) { return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16); }
+__device__ __forceinline__ unsigned gpack2(float a, float b) { return pack_bf16x2(a, b); }
 __device__ __forceinline__ float row16_sum(float v) {          // over the 16 lanes of a lane row (lanes with equal lane >> 4)
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
     return v;

@@ -17,10 +17,10 @@
 namespace occ_gemm_detail {
 
 __device__ __forceinline__ uint4 pack_bf16x8(const float4 lo, const float4 hi) {
-    return make_uint4((unsigned)f32_to_bf16_bits(lo.x) | ((unsigned)f32_to_bf16_bits(lo.y) << 16),
-                      (unsigned)f32_to_bf16_bits(lo.z) | ((unsigned)f32_to_bf16_bits(lo.w) << 16),
-                      (unsigned)f32_to_bf16_bits(hi.x) | ((unsigned)f32_to_bf16_bits(hi.y) << 16),
-                      (unsigned)f32_to_bf16_bits(hi.z) | ((unsigned)f32_to_bf16_bits(hi.w) << 16));
+    return make_uint4(pack_bf16x2(lo.x, lo.y),
+                      pack_bf16x2(lo.z, lo.w),
+                      pack_bf16x2(hi.x, hi.y),
+                      pack_bf16x2(hi.z, hi.w));
 }
 
 // the lo parts of a hi / lo bf16 split of eight f32 values (hi = bf16(v) as pack_bf16x8 gives it, lo = bf16(v - hi))

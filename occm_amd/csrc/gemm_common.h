@@ -82,8 +82,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
             if (HASB) v += bv[i];
             if (AUXM == 1) {
                 uint2 o;
-                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(a.aux + coff + n) = o;
             }
             if (AUXM == 2) {
@@ -96,8 +96,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { float y; gelu_fwd_grad(v[e], y, gq[e]); v[e] = y; }
                 uint2 o;
-                o.x = (unsigned)f32_to_bf16_bits(gq[0]) | ((unsigned)f32_to_bf16_bits(gq[1]) << 16);
-                o.y = (unsigned)f32_to_bf16_bits(gq[2]) | ((unsigned)f32_to_bf16_bits(gq[3]) << 16);
+                o.x = pack_bf16x2(gq[0], gq[1]);
+                o.y = pack_bf16x2(gq[2], gq[3]);
                 *reinterpret_cast<uint2*>(a.aux + coff + n) = o;
             }
             if (AUXM == 4) {
@@ -108,8 +108,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& a, f32x4 (&ac
             if (HASR) v += *reinterpret_cast<const f32x4*>(a.R + (roff + n) * 4);
             if (CBF) {
                 uint2 o;
-                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(a.C + (coff + n) * 2) = o;
             } else {
                 *reinterpret_cast<f32x4*>(a.C + (coff + n) * 4) = v;
@@ -187,8 +187,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
             }
             if (a.aux && a.act == OCC_ACT_GELU) {                       // keep the pre-activation for backward
                 uint2 o;
-                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(a.aux + coff + n) = o;
             }
             if (a.act == OCC_ACT_GELU_GRAD) {
@@ -204,8 +204,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
                 for (int e = 0; e < 4; ++e) { float y; gelu_fwd_grad(v[e], y, gq[e]); v[e] = y; }
                 if (a.aux) {
                     uint2 o;
-                    o.x = (unsigned)f32_to_bf16_bits(gq[0]) | ((unsigned)f32_to_bf16_bits(gq[1]) << 16);
-                    o.y = (unsigned)f32_to_bf16_bits(gq[2]) | ((unsigned)f32_to_bf16_bits(gq[3]) << 16);
+                    o.x = pack_bf16x2(gq[0], gq[1]);
+                    o.y = pack_bf16x2(gq[2], gq[3]);
                     *reinterpret_cast<uint2*>(a.aux + coff + n) = o;
                 }
             } else if (a.act != OCC_ACT_NONE) {
@@ -226,8 +226,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
                 *reinterpret_cast<float4*>(a.C + (coff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 o;
-                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(a.C + (coff + n) * 2) = o;
             }
         }
@@ -295,8 +295,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
                 if (HASB) { v0 += b0; v1 += b1; }
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 auto pack = [&](uint4& o) {
-                    o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16); o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-                    o.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16); o.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+                    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
                 };
                 if (AUXM == 1) {
                     uint4 o; pack(o);
@@ -314,8 +314,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { float y; gelu_fwd_grad(v[e], y, gq[e]); v[e] = y; }
                     uint4 og;
-                    og.x = (unsigned)f32_to_bf16_bits(gq[0]) | ((unsigned)f32_to_bf16_bits(gq[1]) << 16); og.y = (unsigned)f32_to_bf16_bits(gq[2]) | ((unsigned)f32_to_bf16_bits(gq[3]) << 16);
-                    og.z = (unsigned)f32_to_bf16_bits(gq[4]) | ((unsigned)f32_to_bf16_bits(gq[5]) << 16); og.w = (unsigned)f32_to_bf16_bits(gq[6]) | ((unsigned)f32_to_bf16_bits(gq[7]) << 16);
+                    og.x = pack_bf16x2(gq[0], gq[1]); og.y = pack_bf16x2(gq[2], gq[3]);
+                    og.z = pack_bf16x2(gq[4], gq[5]); og.w = pack_bf16x2(gq[6], gq[7]);
                     if (whole) *reinterpret_cast<uint4*>(a.aux + coff) = og;
                     else *reinterpret_cast<uint2*>(a.aux + coff) = make_uint2(og.x, og.y);
                 }
@@ -407,8 +407,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
             if (HASB) v += bv;
             if (AUXM == 1) {
                 uint2 o;
-                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(a.aux + coff) = o;
             }
             if (AUXM == 2) {
@@ -421,8 +421,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { float y; gelu_fwd_grad(v[e], y, gq[e]); v[e] = y; }
                 uint2 o;
-                o.x = (unsigned)f32_to_bf16_bits(gq[0]) | ((unsigned)f32_to_bf16_bits(gq[1]) << 16);
-                o.y = (unsigned)f32_to_bf16_bits(gq[2]) | ((unsigned)f32_to_bf16_bits(gq[3]) << 16);
+                o.x = pack_bf16x2(gq[0], gq[1]);
+                o.y = pack_bf16x2(gq[2], gq[3]);
                 *reinterpret_cast<uint2*>(a.aux + coff) = o;
             }
             if (AUXM == 4) {
@@ -433,8 +433,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_t(const GemmArgs& a, f32x4 (&
             if (HASR) v += rv;
             if (CBF) {
                 uint2 o;
-                o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(a.C + coff * 2) = o;
             } else {
                 *reinterpret_cast<f32x4*>(a.C + coff * 4) = v;

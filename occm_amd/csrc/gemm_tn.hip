@@ -192,8 +192,8 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_bf16_kernel(const TnArgs a) {
         }
     };
     auto pack4 = [](const float4 v) {
-        return make_uint2((unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16),
-                          (unsigned)f32_to_bf16_bits(v.z) | ((unsigned)f32_to_bf16_bits(v.w) << 16));
+        return make_uint2(pack_bf16x2(v.x, v.y),
+                          pack_bf16x2(v.z, v.w));
     };
     // per-lane byte offsets of the transposing reads: row 16h + 4g + q, columns 4p .. 4p+3 of the fragment's 16 columns
     const int q = (lane & 15) >> 2, p = lane & 3;

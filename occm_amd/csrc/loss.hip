@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(void* const* __restrict
         reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
         if (pb) {
             uint2 o;
-            o.x = (unsigned)f32_to_bf16_bits(pv.x) | ((unsigned)f32_to_bf16_bits(pv.y) << 16);
-            o.y = (unsigned)f32_to_bf16_bits(pv.z) | ((unsigned)f32_to_bf16_bits(pv.w) << 16);
+            o.x = pack_bf16x2(pv.x, pv.y);
+            o.y = pack_bf16x2(pv.z, pv.w);
             reinterpret_cast<uint2*>(pb)[i] = o;
         }
     }

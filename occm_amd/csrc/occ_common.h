@@ -38,6 +38,15 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
     return *reinterpret_cast<unsigned short*>(&h);
 }
 
+// two floats -> one dword of bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32.  (Two scalar conversions or-ed together --
+// bits(lo) | bits(hi) << 16 -- compile to four instructions a pair: cvt, cvt, shift, or.)
+typedef __attribute__((ext_vector_type(2))) float occ_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 occ_bf16x2_t;
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const occ_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, occ_bf16x2_t));
+}
+
 template <typename T> __device__ __forceinline__ float occ_load_f32(const T* p);
 template <> __device__ __forceinline__ float occ_load_f32<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float occ_load_f32<unsigned short>(const unsigned short* p) { return bf16_bits_to_f32(*p); }

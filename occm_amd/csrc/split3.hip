@@ -7,7 +7,7 @@
 
 namespace {
 
-__device__ __forceinline__ unsigned pk2(float a, float b) { return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16); }
+__device__ __forceinline__ unsigned pk2(float a, float b) { return pack_bf16x2(a, b); }
 __device__ __forceinline__ float lo_of(float v) { return v - bf16_bits_to_f32(f32_to_bf16_bits(v)); }
 
 // one thread = 8 consecutive elements of a row: two float4 in, three uint4 out

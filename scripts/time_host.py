@@ -26,3 +26,10 @@ for _ in range(n): tr.step(wav, labels, next_wav=wav)
 t_host = (time.perf_counter() - t0) / n
 torch.cuda.synchronize(); t_wall = (time.perf_counter() - t0) / n
 print("%s + %s bs %d: host enqueue %.1f ms per step, wall %.1f ms per step" % (size, backend, bs, t_host * 1e3, t_wall * 1e3))
+# the same enqueue into an EMPTY queue (back to back the host blocks on the launch queue's depth, so the number above is an upper bound)
+ts = []
+for _ in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); tr.step(wav, labels, next_wav=wav); ts.append(time.perf_counter() - t0)
+ts.sort()
+print("   one step enqueued after a synchronize: %.1f ms (median of 5)" % (ts[2] * 1e3))
