@@ -166,7 +166,7 @@ typedef struct occ_gemm_desc {
     void* c_f8; const float* c_f8_scale; float* c_f8_amax; int c_f8_fmt;
     /* Optional column sums of a bf16 result from the same epilogue: c_colsum f32 [N] += sum over rows of the (bf16-rounded) C -- the
      * bias gradient of the layer whose output gradient C is (fc1: C = the gradient through GELU), which otherwise is a pass over C.
-     * c_colsum_ws: caller-owned f32 scratch, >= 2 * ceil(M / 224) * N floats (per-tile partial sums, added in a fixed order by a
+     * c_colsum_ws: caller-owned f32 scratch, >= 2 * ceil(M / 208) * N floats (per-tile partial sums, added in a fixed order by a
      * second small launch).  Same launch restrictions as c_f8.                                                              */
     float* c_colsum; float* c_colsum_ws; int64_t c_colsum_ws_floats;
     int c_colsum_defer;                        /* 1: partial sums only, no finalize launch: see occ_finalize_batch (the caller keeps c_colsum_ws zero-initialised: a launch writes its 2 * ceil(M / tile rows) rows only) */
@@ -191,12 +191,12 @@ int occ_fp8_amax(const void* src, int src_dtype, int64_t n, float* amax, void* s
 int occ_fp8_update_scales(float* amax, float* scale, float* inv_scale, int64_t n, float fmax, float margin, void* stream);
 
 /* Tuning hook: forces one kernel of the bf16 GEMM family instead of the size heuristic (1 = heuristic, the default; 30 = the
- * 256x256 eight-phase kernel, 31 = its 224-row form; 3 = 256x128 LDS-DMA tile; 14 = half-slab pipeline; 22 = in-workgroup split-K); v < 0 only queries.
+ * 256x256 eight-phase kernel, 31 = its 224-row form, 32 = its 208-row form; 3 = 256x128 LDS-DMA tile; 14 = half-slab pipeline; 22 = in-workgroup split-K); v < 0 only queries.
  * Returns the previous value.  Initialised from OCC_GEMM_VARIANT.  Results agree across kernels up to f32 summation order.  */
 int occ_gemm_variant(int v);
 /* Which kernel family the calling thread's last occ_gemm call launched (-1 before the first call): lets tests pin the dispatch. */
 enum { OCC_GEMM_KERNEL_OTHER = 0, OCC_GEMM_KERNEL_P8 = 8, OCC_GEMM_KERNEL_P8_FP8 = 9, OCC_GEMM_KERNEL_P8_TAIL = 10 /* eight-phase kernel + a small-tile launch for the last partial round */,
-       OCC_GEMM_KERNEL_P8_224 = 11 /* eight-phase kernel on 224-row tiles */,
+       OCC_GEMM_KERNEL_P8_224 = 11 /* eight-phase kernel on 224-row (or 208-row) tiles */,
        OCC_GEMM_KERNEL_Q4 = 12 /* four-wave 256 x 128 kernel, two workgroups per CU (csrc/gemm_q4.hip) */ };
 int occ_gemm_last_kernel(void);
 
@@ -464,7 +464,7 @@ int occ_layernorm_bwd_fused(const void* dy, int dy_dtype, const float* x, const 
  * with ONE occ_finalize_batch launch after the backward pass.  Job layouts:
  *   kind 0 (LayerNorm / column sums): partials [n0 rows][n1], out[i] += sum of the rows; i < n2 -> out0, < 2 n2 -> out1, else out2 (may be NULL).
  *           LayerNorm: n0 = min(256, ceil(rows / 48)), n1 = 3 C, n2 = C, outs = dgamma, dbeta, dbias.  GEMM column sums: n0 = 2 ceil(M / tile rows)
- *           (224 or 256, the dispatcher's choice: give n0 = 2 * ceil(M / 224) and keep the buffer zero-initialised), n1 = n2 = N, out0 = c_colsum.
+ *           (208, 224 or 256, the dispatcher's choice: give n0 = 2 * ceil(M / 208) and keep the buffer zero-initialised), n1 = n2 = N, out0 = c_colsum.
  *   kind 1 (attention q|k|v bias, one key block): partials [n0 = B][n1 = H][3][n2 = hd], out0 = dbias [3 * H * hd].
  * n_blocks: kind 0 ceil(n1 / 64), kind 1 3 * n1; first_block = running sum, ascending.                                                */
 typedef struct occ_finalize_job {

@@ -665,8 +665,8 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     a.dq_a = fp8 ? d->a_dequant : nullptr; a.dq_w = fp8 ? d->w_dequant : nullptr;
     a.ksplit = 1; a.slabs_per_split = 0; a.ngroups = 1;
     a.colsum_part = d->c_colsum ? d->c_colsum_ws : nullptr;
-    OCC_CHECK_ARG(!d->c_colsum || (d->c_colsum_ws && ((uintptr_t)d->c_colsum_ws & 15) == 0 && d->c_colsum_ws_floats >= 2 * occ_cdiv(d->M, 224) * d->N && d->c_dtype == OCC_BF16 && !d->R && d->N % 8 == 0),
-                  "occ_gemm: c_colsum needs a bf16 result, no residual, N %% 8 == 0 and 2*ceil(M/224)*N floats of 16-byte aligned scratch");
+    OCC_CHECK_ARG(!d->c_colsum || (d->c_colsum_ws && ((uintptr_t)d->c_colsum_ws & 15) == 0 && d->c_colsum_ws_floats >= 2 * occ_cdiv(d->M, 208) * d->N && d->c_dtype == OCC_BF16 && !d->R && d->N % 8 == 0),
+                  "occ_gemm: c_colsum needs a bf16 result, no residual, N %% 8 == 0 and 2*ceil(M/208)*N floats of 16-byte aligned scratch");
     a.f8_out = (unsigned char*)d->c_f8; a.f8_scale = d->c_f8_scale; a.f8_amax = d->c_f8_amax; a.f8_e5m2 = d->c_f8_fmt == OCC_FP8_E5M2;
     OCC_CHECK_ARG(!d->c_f8 || (d->c_dtype == OCC_BF16 && !d->R && d->N % 8 == 0 && d->c_f8_scale && (d->c_f8_fmt == OCC_FP8_E4M3 || d->c_f8_fmt == OCC_FP8_E5M2)),
                   "occ_gemm: c_f8 needs a bf16 result, no residual, N %% 8 == 0, a scale and an fp8 format");
@@ -724,7 +724,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         OCC_LAUNCH_CHECK("occ_gemm");
         return OCC_OK;
     }
-    if (p8_ok && (variant == 30 || variant == 31 || (variant == 1 && p8_env && nbm256 * occ_cdiv(d->N, 256) * 10 >= 7ll * cu_count()))) {
+    if (p8_ok && (variant == 30 || variant == 31 || variant == 32 || (variant == 1 && p8_env && nbm256 * occ_cdiv(d->N, 256) * 10 >= 7ll * cu_count()))) {
         // One workgroup per CU: a launch takes ceil(tiles / CUs) tile times, so 800 tiles of 256 rows on 256 CUs (fc1 at bs 64) pay four
         // rounds for 3.125 rounds of work and 200 tiles (N = 1024) leave 56 CUs idle.  Three forms, costed in tile-row units:
         //   whole   ceil(tiles256 / CUs) * 256
@@ -740,8 +740,20 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         const bool can_tail = !d->c_f8 && !d->c_colsum && variant == 1 && tail_env && tiles > cus && rem > 0 && rem * 2 <= cus && nbm1 >= 1 && nbm1 < nbm256 &&
                               rows_rebase(d->a_map, d->M, m1, &oa) && rows_rebase(d->c_map, d->M, m1, &oc) && (!d->R || rows_rebase(d->r_map, d->M, m1, &orr));
         const bool can_224 = rows_epilogue_applies(a) && (variant == 31 || (variant == 1 && r224_env));
+        //   208     62 row tiles at M = 12736 (the lower wave row a block shorter): 248 / 744 / 992 workgroups = the same rounds, 13/14 of the loop
+        static const int r208_env = getenv("OCC_GEMM_208") ? atoi(getenv("OCC_GEMM_208")) : 1;
+        const bool can_208 = rows_epilogue_applies(a) && !d->c_f8 && (variant == 32 || (variant == 1 && r208_env));
         const long long cost_whole = occ_cdiv(tiles, cus) * 256, cost_tail = can_tail ? (tiles / cus) * 256 + 200 : (1ll << 40),
-                        cost_224 = can_224 ? occ_cdiv(occ_cdiv(d->M, 224) * nbn256, cus) * 224 : (1ll << 40);
+                        cost_224 = can_224 ? occ_cdiv(occ_cdiv(d->M, 224) * nbn256, cus) * 224 : (1ll << 40),
+                        cost_208 = can_208 ? occ_cdiv(occ_cdiv(d->M, 208) * nbn256, cus) * 208 : (1ll << 40);
+        if (variant == 32 || (variant != 31 && cost_208 < cost_whole && cost_208 < cost_tail && cost_208 < cost_224)) {
+            OCC_CHECK_ARG(can_208, "occ_gemm: the 208-row tile has no epilogue for this combination");
+            g_last_kernel = OCC_GEMM_KERNEL_P8_224;                 // (reported with the 224-row form: the same kernel, a shorter lower wave row)
+            gemm_p8_launch(a, s, 0, 208);
+            if (d->c_colsum && !d->c_colsum_defer) colsum_finalize(a, d->c_colsum, s);
+            OCC_LAUNCH_CHECK("occ_gemm");
+            return OCC_OK;
+        }
         if (variant == 31 || (cost_224 < cost_whole && cost_224 < cost_tail)) {
             OCC_CHECK_ARG(can_224, "occ_gemm: the 224-row tile has no epilogue for this combination");
             g_last_kernel = OCC_GEMM_KERNEL_P8_224;

@@ -37,9 +37,11 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #define P8_QUAD(NH, MH, WQ)                                                                        \
     __builtin_amdgcn_s_setprio(1);                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                               \
-        _Pragma("unroll") for (int mf = 0; mf < ((MH) ? MB - 4 : 4); ++mf)                         \
+        _Pragma("unroll") for (int mf = 0; mf < ((MH) ? MB - 4 : 4); ++mf) {                       \
+            if (ASYM && (MH) && mf == MB - 5 && wr == 1) continue;   /* the lower wave row's last block is not part of a 208-row tile */ \
             _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                       \
                 P8_MFMA(acc[(NH) * 2 + nf][(MH) * 4 + mf], WQ[nf][ks], x[mf][ks]);                 \
+        }                                                                                          \
     __builtin_amdgcn_s_setprio(0);                                                                 \
     __builtin_amdgcn_sched_barrier(0);
 
@@ -75,9 +77,13 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 // of the second m-half is neither multiplied nor stored).  M = 12736 (bs 64) is 49.75 tiles of 256 rows: with N = 1024 that is 200
 // workgroups for 256 CUs, and 600 / 800 for N = 3072 / 4096 -- 57 tiles of 224 rows make it 228 / 684 / 912, the same number of rounds
 // of a tile that costs 7/8.
-template <int FMT, int MB = 8>
+// ASYM (MB = 7, bf16): 208-row tiles -- the upper wave row keeps its 7 blocks (112 rows), the lower one multiplies and stores 6 (96 rows;
+// its tile rows start at 112 as before).  The two waves of a SIMD share its matrix core, so a K-tile costs 13/14 of the 224-row form's
+// MFMAs: 62 row tiles at M = 12736 = 248 / 744 / 992 workgroups -- one, three and four rounds again, of a shorter loop.
+template <int FMT, int MB = 8, bool ASYM = false>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
     static_assert(MB == 8 || MB == 7, "8 or 7 blocks of 16 rows per wave");
+    static_assert(!ASYM || (MB == 7 && FMT == 0), "the 208-row form is the bf16 224-row kernel with a shorter lower wave row");
     constexpr int ES = FMT == 0 ? 2 : 1;           // bytes per operand element; a K-tile is 128 bytes of every row
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 65536];
     const int total = a.nbm * a.nbn;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
         tile_m = first_m + loc % gsz;
         tile_n = loc / gsz;
     }
-    const long long m0 = (long long)tile_m * (MB * 32), n0 = (long long)tile_n * 256;
+    const long long m0 = (long long)tile_m * (ASYM ? 208 : MB * 32), n0 = (long long)tile_n * 256;
 #ifdef P8_DIAG
     const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
     const unsigned long long dg_t2 = __builtin_amdgcn_s_memtime();
 #endif
     // all LDS is free here: no DMA is outstanding (the last phase waited vmcnt(0)) and every wave has finished its fragment reads
-    gemm_epilogue_rows<8>(a, acc, m0 + wr * (MB * 16), n0 + wc * 64, lane, 0, lds + wave * 16384, MB * 16, tile_m * 2 + wr);
+    gemm_epilogue_rows<8>(a, acc, m0 + wr * (MB * 16), n0 + wc * 64, lane, 0, lds + wave * 16384, ASYM && wr == 1 ? 96 : MB * 16, tile_m * 2 + wr);
 #ifdef P8_DIAG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
@@ -272,6 +278,10 @@ void gemm_p8_launch(GemmArgs& a, hipStream_t s, int fmt, int tile_rows) {
     a.nbn = (int)occ_cdiv(a.N, 256);
     a.group_m = a.nbm >= 8 ? 8 : 0;
     const dim3 grid((unsigned)((long long)a.nbm * a.nbn));
+    if (tile_rows == 208) {
+        hipLaunchKernelGGL((gemm_p8_kernel<0, 7, true>), grid, dim3(512), 0, s, a);        // (bf16 only: the caller checks)
+        return;
+    }
     if (tile_rows == 224) {
         if (fmt == 0) hipLaunchKernelGGL((gemm_p8_kernel<0, 7>), grid, dim3(512), 0, s, a);
         else if (fmt == 1) hipLaunchKernelGGL((gemm_p8_kernel<1, 7>), grid, dim3(512), 0, s, a);

@@ -799,7 +799,7 @@ class XlsrFineTuner(XlsrFrontend):
     # backward pass, or per layer when a data-parallel caller wants the layer's gradients final for its all-reduce (grad_ready).
     def _fin_site(self, site, nfloats, zero_tag=None):
         """This site's partial-sum buffer.  zero_tag (the GELU' column sums): the producer may write FEWER partial rows than the job sums --
-        occ_gemm picks 224- or 256-row tiles, the job counts rows for the smaller -- so the buffer starts as zeros and is cleared again
+        occ_gemm picks 208-, 224- or 256-row tiles, the job counts rows for the smallest -- so the buffer starts as zeros and is cleared again
         whenever the launch shape (zero_tag) changes: rows the kernel of one shape never writes then always read as zero."""
         if not self.defer_finalize:
             return None
@@ -1055,9 +1055,9 @@ class XlsrFineTuner(XlsrFrontend):
             colsum = None
             if fc1_bias_fused:
                 colsum = self.mg["l%d.fc1.b" % i]
-                part = self._fin_site("fc1.%d" % i, 2 * ((M + 223) // 224) * Fd, zero_tag=(M, Fd, D, bool(getattr(self, "fp8", False))))
+                part = self._fin_site("fc1.%d" % i, 2 * ((M + 207) // 208) * Fd, zero_tag=(M, Fd, D, bool(getattr(self, "fp8", False))))
                 if part is not None:
-                    self._fin_build.add_rows(part, 2 * ((M + 223) // 224), colsum)
+                    self._fin_build.add_rows(part, 2 * ((M + 207) // 208), colsum)
                     colsum = (colsum, part)
             self._dgrad(i, "fc2.w", dyb, "g_fc2", M, Fd, D, tr["du"], act=ACT_MUL_AUX if KEEP_GELU_GRAD else ACT_GELU_GRAD, aux=s["u"], f8_next="g_fc1" if p_act == 0 else None,
                         colsum=colsum)

@@ -66,7 +66,7 @@ def gemm_raw(M, N, K, A, a_map, W, ldw, C, c_map, c_dtype, ab_dtype, bias=None, 
             c_colsum, ws = c_colsum
             d.c_colsum_defer = 1
         else:
-            ws = small_scratch(2 * ((int(M) + 223) // 224) * int(N))          # one partial row per 112-row half tile (occ_gemm checks the size)
+            ws = small_scratch(2 * ((int(M) + 207) // 208) * int(N))          # one partial row per wave row of a tile; 208 rows = the smallest tile (occ_gemm checks the size)
         d.c_colsum, d.c_colsum_ws, d.c_colsum_ws_floats = c_colsum.data_ptr(), ws.data_ptr(), ws.numel()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -372,8 +372,8 @@ class FinalizeBatch:
 
     def add_rows(self, partials, n_rows, out0, out1=None, out2=None, C=None):
         """kind 0: out[i] += sum over n_rows rows of partials [n_rows, tot]; i < C -> out0, < 2C -> out1, else out2 (tot = C * number of outs given).
-        For gemm_raw(c_colsum=(out, ws)) pass n_rows = 2 * ceil(M / 224) and a ws that started as ZEROS: occ_gemm writes 2 * ceil(M / tile rows)
-        partial rows with 224- or 256-row tiles (its own choice per shape); the rows it does not write must read as zero."""
+        For gemm_raw(c_colsum=(out, ws)) pass n_rows = 2 * ceil(M / 208) and a ws that started as ZEROS: occ_gemm writes 2 * ceil(M / tile rows)
+        partial rows with 208-, 224- or 256-row tiles (its own choice per shape); the rows it does not write must read as zero."""
         C = int(C if C is not None else out0.numel())
         tot = C * (1 + (out1 is not None) + (out2 is not None))
         if out2 is not None and out1 is None:

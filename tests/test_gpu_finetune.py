@@ -653,9 +653,9 @@ def test_deferred_finalizes_in_one_launch_equal_the_per_site_finalizes():
         run = lambda **kw: ops.gemm_raw(M, N, K, xa, ops.rowmap(M, 0, K), w, K, Cm, ops.rowmap(M, 0, N), OCC_BF16, OCC_BF16, act=ACT_GELU_GRAD, aux=u, **kw)
         want = torch.full((N,), 0.25, device="cuda"); run(c_colsum=want)
         got = torch.full((N,), 0.25, device="cuda")
-        part = torch.zeros(2 * ((M + 223) // 224) * N, device="cuda")            # zeros: the launch may write fewer rows than the job sums (256-row tiles)
+        part = torch.zeros(2 * ((M + 207) // 208) * N, device="cuda")            # zeros: the launch may write fewer rows than the job sums (224- / 256-row tiles)
         run(c_colsum=(got, part))
-        fb.add_rows(part, 2 * ((M + 223) // 224), got)
+        fb.add_rows(part, 2 * ((M + 207) // 208), got)
         checks.append((got, want))
     # the attention backward's q|k|v bias sums
     for B, T, H, hd in ((5, 199, 4, 64), (64, 199, 16, 64), (3, 61, 3, 80)):

@@ -72,6 +72,42 @@ def test_p8_224_row_tiles_exact(M, N, K):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (417, 256, 128), (624, 256, 128), (416, 512, 192), (1000, 512, 1024), (12736, 1024, 1024), (2049, 260, 448), (6368, 1280, 1280)])
+def test_p8_208_row_tiles_exact(M, N, K):
+    """Variant 32: 208-row tiles -- the upper wave row's 7 blocks (112 rows) and 6 of the lower one's (96 rows).  Exact integer products in
+    a pre-filled output compared whole (a row written twice, skipped, or taken from the neighbouring tile shows), bf16 output with GELU +
+    saved pre-activation and the GELU' column sums against the 256-row kernel bit for bit."""
+    from occm_amd import ops
+    from occm_amd._lib import lib
+    x, w = _ints(M, K, 1), _ints(N, K, 2)
+    bias = _ints(1, N, 3)[0]
+    ref = x.double() @ w.double().T + bias.double()
+    xb, wb = x.bfloat16().cuda(), w.bfloat16().cuda()
+    u = _ints(M, N, 4, -2, 2).bfloat16().cuda()
+    res = []
+    prev = lib().occ_gemm_variant(-1)
+    try:
+        for variant in (32, 30):
+            lib().occ_gemm_variant(variant)
+            out = torch.full((M, N), 7777.0, device="cuda")
+            ops.gemm_raw(M, N, K, xb, ops.rowmap(M, 0, K), wb, K, out, ops.rowmap(M, 0, N), ops.OCC_F32, ops.OCC_BF16, bias=bias.cuda())
+            assert lib().occ_gemm_last_kernel() == (11 if variant == 32 else 8)
+            assert torch.equal(out.cpu().double(), ref), (variant, float((out.cpu().double() - ref).abs().max()))
+            o16 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16); aux = torch.zeros_like(o16)
+            ops.gemm_raw(M, N, K, xb, ops.rowmap(M, 0, K), wb, K, o16, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16, bias=bias.cuda(), act=ops.ACT_GELU, aux=aux, alpha=1.0 / 64)
+            cs = torch.full((N,), 0.5, device="cuda")
+            du = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+            if N % 8 == 0:
+                ops.gemm_raw(M, N, K, xb, ops.rowmap(M, 0, K), wb, K, du, ops.rowmap(M, 0, N), ops.OCC_BF16, ops.OCC_BF16, act=ops.ACT_MUL_AUX, aux=u, c_colsum=cs)
+            res.append((o16, aux, du, cs))
+    finally:
+        lib().occ_gemm_variant(prev)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    if N % 8 == 0:                         # the same bf16 values summed over other row ranges: equal to f32 round-off
+        torch.testing.assert_close(res[0][3], res[1][3], rtol=1e-5, atol=1e-2)
+        assert float((res[0][3] - 0.5).abs().max()) > 0
+
+
 def test_tail_split_matches_single_launch_exactly():
     """800 tiles on 256 CUs.  With a row-layout epilogue the heuristic takes 224-row tiles; without one (bf16 residual) it runs 48 row
     tiles in the eight-phase kernel and rows 12288.. through the small-tile kernels.  Integer operands make every form exact, so the

@@ -356,11 +356,14 @@ def test_scoring_300m_24_layers_f32_and_bf16_paths_vs_oracle_chain(tmp_path, mon
 
 
 @pytest.mark.parametrize("T,H,hd,dt", [(50, 4, 64, torch.float32), (199, 16, 64, torch.float32), (343, 4, 64, torch.float32), (700, 2, 64, torch.float32),
-                                       (700, 2, 80, torch.float32), (1030, 1, 128, torch.float32), (420, 4, 64, torch.bfloat16)])
+                                       (700, 2, 80, torch.float32), (1030, 1, 128, torch.float32), (420, 4, 64, torch.bfloat16),
+                                       # block edges of the f32 matrix-core kernel (64 queries per workgroup, keys in blocks of 64, 16-key tiles)
+                                       (8, 1, 64, torch.float32), (64, 2, 64, torch.float32), (65, 2, 80, torch.float32), (129, 3, 64, torch.float32)])
 def test_f32_attention_any_length_and_key_masks(T, H, hd, dt):
     """occ_attention on the f32 scoring path used to stop at ~300 frames (K and V of a head in LDS); utterances of the ASVspoof eval lists
-    run to 13 s (650 frames).  The streaming kernel (keys in blocks of 64, online softmax) takes over beyond that, and occ_attention_varlen
-    masks the pad keys of a zero-padded batch: rows [0, len_b) of every utterance against torch's softmax attention of the un-padded rows."""
+    run to 13 s (650 frames).  The streaming kernels (keys in blocks of 64, online softmax: on the f32 matrix cores for f32 storage and head
+    dims 64 / 80 -- csrc/attention_f32.hip --, the VALU form otherwise) take any length, and occ_attention_varlen masks the pad keys of a
+    zero-padded batch: rows [0, len_b) of every utterance against torch's softmax attention of the un-padded rows."""
     from occm_amd import ops
     B, D = 3, H * hd
     g = torch.Generator().manual_seed(T + hd)
