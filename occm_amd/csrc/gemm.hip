@@ -698,7 +698,20 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
     if (fp8) {                                  // the only fp8 kernel (any size: edge tiles are clamped / masked as for bf16)
         OCC_CHECK_ARG(p8_fits, "occ_gemm: fp8 operands too large for 32-bit DMA offsets");
         g_last_kernel = OCC_GEMM_KERNEL_P8_FP8;
-        gemm_p8_launch(a, s, d->ab_dtype == OCC_FP8_E4M3 ? 1 : 2);
+        // tile height by rounds x rows, as for bf16 below (until late round 4 fp8 always took 256-row tiles: 200 / 600 / 800 workgroups for
+        // 256 CUs at M = 12736 -- one, three and four rounds at 78 % fill)
+        static const int f8_rows_env = getenv("OCC_GEMM_FP8_ROWS") ? atoi(getenv("OCC_GEMM_FP8_ROWS")) : 0;     // 256 / 224 / 208 forces one; 0 = by cost
+        int f8_rows = 256;
+        if (rows_epilogue_applies(a)) {
+            const long long nbn = occ_cdiv(d->N, 256), cus = cu_count();
+            long long best = occ_cdiv(nbm256 * nbn, cus) * 256;
+            for (const int r : {224, 208}) {
+                const long long c = occ_cdiv(occ_cdiv(d->M, r) * nbn, cus) * r;
+                if (c < best) { best = c; f8_rows = r; }
+            }
+            if (f8_rows_env == 256 || f8_rows_env == 224 || f8_rows_env == 208) f8_rows = f8_rows_env;
+        }
+        gemm_p8_launch(a, s, d->ab_dtype == OCC_FP8_E4M3 ? 1 : 2, f8_rows);
         if (d->c_colsum && !d->c_colsum_defer) colsum_finalize(a, d->c_colsum, s);
         OCC_LAUNCH_CHECK("occ_gemm");
         return OCC_OK;
@@ -742,7 +755,7 @@ extern "C" int occ_gemm(const occ_gemm_desc* d, void* stream) {
         const bool can_224 = rows_epilogue_applies(a) && (variant == 31 || (variant == 1 && r224_env));
         //   208     62 row tiles at M = 12736 (the lower wave row a block shorter): 248 / 744 / 992 workgroups = the same rounds, 13/14 of the loop
         static const int r208_env = getenv("OCC_GEMM_208") ? atoi(getenv("OCC_GEMM_208")) : 1;
-        const bool can_208 = rows_epilogue_applies(a) && !d->c_f8 && (variant == 32 || (variant == 1 && r208_env));
+        const bool can_208 = rows_epilogue_applies(a) && (variant == 32 || (variant == 1 && r208_env));
         const long long cost_whole = occ_cdiv(tiles, cus) * 256, cost_tail = can_tail ? (tiles / cus) * 256 + 200 : (1ll << 40),
                         cost_224 = can_224 ? occ_cdiv(occ_cdiv(d->M, 224) * nbn256, cus) * 224 : (1ll << 40),
                         cost_208 = can_208 ? occ_cdiv(occ_cdiv(d->M, 208) * nbn256, cus) * 208 : (1ll << 40);

@@ -52,9 +52,11 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
     asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] blgp:" #XT : "+v"(ACC) : "v"(WF), "v"(XF), "v"(unit_scales));
 #define P8_QUAD_F8(NH, MH, WQ, XT)                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                 \
-    _Pragma("unroll") for (int mf = 0; mf < ((MH) ? MB - 4 : 4); ++mf)                             \
+    _Pragma("unroll") for (int mf = 0; mf < ((MH) ? MB - 4 : 4); ++mf) {                           \
+        if (ASYM && (MH) && mf == MB - 5 && wr == 1) continue;       /* (208-row tiles: see P8_QUAD) */ \
         _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                           \
             P8_MFMA_F8(acc[(NH) * 2 + nf][(MH) * 4 + mf], WQ[nf], xq[mf], XT)                      \
+    }                                                                                              \
     __builtin_amdgcn_s_setprio(0);                                                                 \
     __builtin_amdgcn_sched_barrier(0);
 #define P8_Q(NH, MH, WQ)                                                                           \
@@ -77,13 +79,13 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 // of the second m-half is neither multiplied nor stored).  M = 12736 (bs 64) is 49.75 tiles of 256 rows: with N = 1024 that is 200
 // workgroups for 256 CUs, and 600 / 800 for N = 3072 / 4096 -- 57 tiles of 224 rows make it 228 / 684 / 912, the same number of rounds
 // of a tile that costs 7/8.
-// ASYM (MB = 7, bf16): 208-row tiles -- the upper wave row keeps its 7 blocks (112 rows), the lower one multiplies and stores 6 (96 rows;
+// ASYM (MB = 7): 208-row tiles -- the upper wave row keeps its 7 blocks (112 rows), the lower one multiplies and stores 6 (96 rows;
 // its tile rows start at 112 as before).  The two waves of a SIMD share its matrix core, so a K-tile costs 13/14 of the 224-row form's
 // MFMAs: 62 row tiles at M = 12736 = 248 / 744 / 992 workgroups -- one, three and four rounds again, of a shorter loop.
 template <int FMT, int MB = 8, bool ASYM = false>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs a) {
     static_assert(MB == 8 || MB == 7, "8 or 7 blocks of 16 rows per wave");
-    static_assert(!ASYM || (MB == 7 && FMT == 0), "the 208-row form is the bf16 224-row kernel with a shorter lower wave row");
+    static_assert(!ASYM || MB == 7, "the 208-row form is the 224-row kernel with a shorter lower wave row");
     constexpr int ES = FMT == 0 ? 2 : 1;           // bytes per operand element; a K-tile is 128 bytes of every row
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 65536];
     const int total = a.nbm * a.nbn;
@@ -279,7 +281,9 @@ void gemm_p8_launch(GemmArgs& a, hipStream_t s, int fmt, int tile_rows) {
     a.group_m = a.nbm >= 8 ? 8 : 0;
     const dim3 grid((unsigned)((long long)a.nbm * a.nbn));
     if (tile_rows == 208) {
-        hipLaunchKernelGGL((gemm_p8_kernel<0, 7, true>), grid, dim3(512), 0, s, a);        // (bf16 only: the caller checks)
+        if (fmt == 0) hipLaunchKernelGGL((gemm_p8_kernel<0, 7, true>), grid, dim3(512), 0, s, a);
+        else if (fmt == 1) hipLaunchKernelGGL((gemm_p8_kernel<1, 7, true>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((gemm_p8_kernel<2, 7, true>), grid, dim3(512), 0, s, a);
         return;
     }
     if (tile_rows == 224) {
