@@ -539,7 +539,11 @@ def test_finetune_loop_three_steps_track_the_oracle_loop():
         lc, ld = tr.step(w.cuda(), labels.cuda())
         got.append((float(lc), float(ld)))
     for step, ((rc, rd), (gc, gd)) in enumerate(zip(ref_losses, got)):
-        tol = 2e-2 if step == 0 else 8e-2
+        # step 0: the same weights on both sides.  Afterwards every element has moved by about +-lr (Adam's first updates are sign-like), so a
+        # gradient element that differs in its last bits -- bf16 GEMMs, f32 atomics whose order changes run to run -- can flip an update: the
+        # device run is not even equal to ITSELF from run to run there (third-step descriptiveness loss 0.80-0.89 over eight runs of one build
+        # against the oracle's 0.888), and the bound widens with every step
+        tol = (2e-2, 8e-2, 1.5e-1)[step]
         assert abs(gc - rc) <= tol * abs(rc) and abs(gd - rd) <= tol * abs(rd), (step, ref_losses, got)
     sd = model.state_dict()
     worst, worst_sign = 1.0, 1.0
