@@ -43,9 +43,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
                                                        unsigned char* __restrict__ yq = nullptr, const float* __restrict__ f8_scale = nullptr,
                                                        float* __restrict__ f8_amax = nullptr) {
     __shared__ float wmx[F8 ? 4 : 1];
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     float f8max = 0.f;
-    if (row < rows) {
+    // (F8: a grid-stride loop over the row groups, so that a launch ends in ~1000 guarded |max| updates of ONE address instead of one per
+    // four rows -- 3184 of them serialised in the L2 for 22 of the kernel's 54 us at [12736, 1024])
+    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
     const int lane = threadIdx.x & 63;
     const TI* xr = x + row * C;
     float v[NIT][8];
@@ -865,7 +866,10 @@ int occ_layernorm_fp8(const float* x, void* y_bf16, void* y_f8, const float* f8_
                       int64_t C, float eps, void* stream) {
     OCC_CHECK_ARG(x && y_bf16 && y_f8 && f8_scale && f8_amax && gamma && beta, "occ_layernorm_fp8: null pointer");
     OCC_CHECK_ARG(rows >= 1 && C >= 8 && C % 8 == 0 && C <= 2048, "occ_layernorm_fp8: C must be a multiple of 8 in [8,2048] (C=%ld)", (long)C);
-    const dim3 grid((unsigned)occ_cdiv(rows, 4)), block(256);
+    static const long long ln8_blocks = getenv("OCC_LN8_BLOCKS") ? atoll(getenv("OCC_LN8_BLOCKS")) : 1024;      // 4 resident workgroups of 4 rows per CU
+    long long nblk = occ_cdiv(rows, 4);
+    if (nblk > ln8_blocks) nblk = ln8_blocks;
+    const dim3 grid((unsigned)nblk), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define OCC_LN8(N) hipLaunchKernelGGL((layernorm_kernel<float, unsigned short, N, true>), grid, block, 0, s, x, (unsigned short*)y_bf16, gamma, beta, (long long)rows, (int)C, eps, 0, (unsigned char*)y_f8, f8_scale, f8_amax)
     switch ((C + 511) / 512) { case 1: OCC_LN8(1); break; case 2: OCC_LN8(2); break; case 3: OCC_LN8(3); break; default: OCC_LN8(4); }
