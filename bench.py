@@ -425,9 +425,9 @@ def main():
                                       else "SE-ResNet34 fwd+bwd, f32 storage, bf16-MFMA convolutions and weight gradients (f32 accumulate), Adam lr=1e-5"),
                           "gradient_exchange": "none (1 rank)" if world == 1 else "RCCL all-reduce of the flat gradients (%s on the wire, f32 accumulation), per transformer layer, overlapped with backward; NCCL_MAX_NCHANNELS=%s" % (args.grad_wire, os.environ.get("NCCL_MAX_NCHANNELS", "default")),
                           "loss": "%.1f*compactness + %.1f*descriptiveness (%s)" % (wc, wd, "oc_training.py:380-381" if args.backend == "aasist" else "test_dataloader_v2.py:127"),
-                          **({"configs4_note": "one GPU's shard (bs 32 of 256) of BASELINE configs[4]; measured, fp8 ties bf16 at these widths (the fp8 GEMMs' saving is "
-                                               "spent on quantisation passes and the weight gradients stay bf16: DESIGN.md section 5), so configs[4] is RUN IN BF16 and "
-                                               "--fp8 is an accuracy-tested option, not the faster path"} if args.xlsr == "1b" else {}),
+                          **({"configs4_note": "one GPU's shard (bs 32 of 256) of BASELINE configs[4]; measured, fp8 is 1-2 % ahead of bf16 at these widths (most of the "
+                                               "fp8 GEMMs' saving is spent on quantisation passes and the weight gradients stay bf16: DESIGN.md section 5), within the "
+                                               "pool's box-to-box spread: configs[4] is RUN IN BF16 by default and --fp8 is an accuracy-tested option"} if args.xlsr == "1b" else {}),
                           "final_loss_d": round(loss_d, 5), "gemm_src_sha16": gemm_source_sha()},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
